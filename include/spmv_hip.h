@@ -1,0 +1,157 @@
+/*
+ * spmv_hip.h -- C ABI of libspmv_hip.so: the MI355X (gfx950) fp32 CSR SpMV hot path.
+ *
+ * This is the drop-in boundary underneath the reference's launcher surface
+ * (/root/reference/src/include/kernel.hpp:8-17).  The reference launchers are
+ * C++ free functions that take a dense host matrix; include/kernel.hpp in this
+ * repo re-declares them unchanged and spmv-test_amd/host/launchers.cpp
+ * implements them on top of the entry points below.  Every entry point is
+ * extern "C", takes plain pointers and sizes, and returns 0 on success or a
+ * negative spmv_status code; spmv_last_error() then holds a message.  Nothing
+ * here falls back to the CPU: without a HIP device every compute entry point
+ * fails with SPMV_ERR_NO_DEVICE.
+ *
+ * Conventions (from matrix_csr.cpp:8-22):
+ *   CSR row i   = output index i in [0, rows)   (column i of the dense A)
+ *   column idx  = input index j in [0, cols)    (row j of the dense A)
+ *   y[i] = sum_k vals[k] * x[col_idx[k]],  k in [row_ptr[i], row_ptr[i+1])
+ *   row_ptr has rows+1 int32 entries (row_ptr[rows] == nnz); the reference's
+ *   CSRMatrix omits the last one and csr_naive.cu:15 substitutes nnz for it.
+ *   nnz < 2^31 per handle; larger problems are row-block shards, one handle each.
+ */
+#ifndef SPMV_HIP_H
+#define SPMV_HIP_H
+
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define SPMV_API __attribute__((visibility("default")))
+#else
+#define SPMV_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spmv_csr spmv_csr_t;
+
+enum spmv_status {
+    SPMV_OK = 0,
+    SPMV_ERR_NO_DEVICE = -1, /* no HIP device visible: there is no CPU path      */
+    SPMV_ERR_INVALID = -2,   /* bad argument (null, negative size, misaligned)   */
+    SPMV_ERR_HIP = -3,       /* a HIP runtime call failed (message has details)  */
+    SPMV_ERR_VARIANT = -4,   /* unknown variant id (reference: silently no-op,   */
+                             /* wsp.cu:187 -- here it is reported)               */
+    SPMV_ERR_NOT_PLANNED = -5
+};
+
+/* Kernel variants.  The right-hand column is the reference slot each one
+ * replaces (file:line in /root/reference) -- same role, re-derived for CSR on
+ * 64-lane wavefronts, not a translation of the bitmap kernels. */
+enum spmv_variant {
+    SPMV_SCALAR = 0,    /* thread per row, k ascending, mul+add unfused:           */
+                        /*   csr_naive_kernel      src/kernels/csr_naive.cu:6-23   */
+                        /*   (bit-identical to SgemvCPU, src/tester.cpp:36-45)     */
+    SPMV_WAVE = 1,      /* one 64-lane wavefront per row, __shfl_down reduction:   */
+                        /*   wsp_kernel_v0         src/kernels/wsp.cu:4-56         */
+    SPMV_WAVE_PIPE = 2, /* same, 4-deep unrolled loads (software pipeline):        */
+                        /*   wsp_kernel_v1         src/kernels/wsp.cu:59-138       */
+    SPMV_VECTOR = 3,    /* 2..32-lane groups per row, width from mean row length:  */
+                        /*   asp_kernel_v0/1/2     src/kernels/asp.cu:6-211        */
+    SPMV_ADAPTIVE = 4,  /* nnz-balanced chunks, products staged in LDS, per-chunk  */
+                        /* adaptive row reduction, deterministic carry fix-up:     */
+                        /*   awsp_kernel_v0/1/2    src/kernels/awsp.cu:5-317,      */
+                        /*   awsp_ref_kernel       src/kernels/awsp_ref.cu:6-185   */
+    SPMV_TILED = 5,     /* ADAPTIVE + the chunk's window of x staged in LDS:       */
+                        /*   csr_tiling_kernel     src/kernels/csr_tiling.cu:24-114,*/
+                        /*   wsp_sm_kernel         src/kernels/wsp_sm.cu:6-211     */
+    SPMV_VARIANT_COUNT = 6
+};
+
+/* ---- runtime ---------------------------------------------------------- */
+SPMV_API int spmv_device_count(void);            /* >= 0; 0 when no HIP device is usable */
+SPMV_API const char *spmv_last_error(void);      /* thread-local, never NULL             */
+SPMV_API const char *spmv_variant_name(int variant);
+
+/* ---- matrix handles ---------------------------------------------------
+ * replaces: CSRMatrix (src/matrix_csr.cpp:5-23, src/include/matrix_csr.hpp:4-25)
+ * and the cudaMalloc/cudaMemcpy block of every launcher (e.g. csr_naive.cu:36-52). */
+
+/* Copy host CSR arrays to the current device (owned by the handle). */
+SPMV_API int spmv_csr_create_host(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
+                         const int32_t *col_idx, const float *vals, spmv_csr_t **out);
+
+/* Borrow device arrays (caller keeps them alive; col_idx/vals 16-byte aligned). */
+SPMV_API int spmv_csr_create_device(int64_t rows, int64_t cols, int64_t nnz, const int32_t *d_row_ptr,
+                           const int32_t *d_col_idx, const float *d_vals, spmv_csr_t **out);
+
+/* Dense row-major host A[M][N] -> CSR of A^T, built ON THE DEVICE with the
+ * reference's semantics (keep iff value != 0.0f, columns ascending):
+ * replaces the O(MN) host scan of matrix_csr.cpp:5-23.  rows = N, cols = M. */
+SPMV_API int spmv_csr_from_dense_host(int M, int N, const float *A_host, void *stream, spmv_csr_t **out);
+
+/* Same with A already resident on the device. */
+SPMV_API int spmv_csr_from_dense_device(int M, int N, const float *d_A, void *stream, spmv_csr_t **out);
+
+/* Copy the handle's CSR arrays back (row_ptr: rows+1 entries).  Any pointer may be NULL. */
+SPMV_API int spmv_csr_download(const spmv_csr_t *h, int32_t *row_ptr, int32_t *col_idx, float *vals);
+
+SPMV_API int spmv_csr_dims(const spmv_csr_t *h, int64_t *rows, int64_t *cols, int64_t *nnz);
+SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
+
+/* ---- the hot path ------------------------------------------------------
+ * spmv_csr_plan: one-off device-side preprocessing a variant needs (chunk
+ * boundaries, column windows); a no-op for SCALAR/WAVE.  Excluded from the
+ * timed SpMV like the reference excludes its host format build from
+ * TIME_KERNEL (e.g. wsp.cu:146 vs :167).
+ * spmv_csr_run: enqueue y = A x on `stream` (a hipStream_t, NULL = default).
+ * Asynchronous; d_x has cols floats, d_y has rows floats and is fully
+ * overwritten.  No allocation, no synchronisation: graph-capturable. */
+SPMV_API int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream);
+SPMV_API int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void *stream);
+
+/* Bytes of plan metadata the variant reads per run (not credited as algorithmic bytes). */
+SPMV_API int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant);
+
+/* Run `iters` back-to-back launches on `stream` between two HIP events
+ * recorded on that same stream; returns the mean milliseconds per launch.
+ * replaces: TIME_KERNEL (src/include/kernel.hpp:31-48). */
+SPMV_API int spmv_csr_time(spmv_csr_t *h, int variant, const float *d_x, float *d_y, int iters,
+                  void *stream, float *ms_per_launch);
+
+/* Host-buffer convenience used by the C++ launchers: upload x (cols floats),
+ * plan if needed, run once between HIP events, download y (rows floats).
+ * Synchronous.  *kernel_ms (may be NULL) receives the event time of the run.
+ * replaces: the malloc/memcpy/TIME_KERNEL/memcpy/free body of a reference
+ * launcher (e.g. csr_naive.cu:36-73). */
+SPMV_API int spmv_csr_run_host(spmv_csr_t *h, int variant, const float *x_host, float *y_host,
+                               float *kernel_ms);
+
+/* ---- dense baselines (reference slots cublas / naive / tiling) ---------
+ * y[i] = sum_j x[j] * A[j*N+i] on the dense device matrix.
+ * replaces: cublas_gemv_gpu (cublas.cu:4-44), naive_kernel (naive.cu:4-11),
+ * tiling_kernel (tiling_smem.cu:4-32).  mode 0 = thread per output (naive),
+ * 1 = LDS-staged x tile (tiling), 2 = split-M wave-coalesced (vendor slot). */
+SPMV_API int spmv_dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode,
+                    void *stream);
+
+/* Host-buffer form of the same (upload A and x, run, download y). */
+SPMV_API int spmv_dense_gemv_host(int M, int N, const float *A_host, const float *x_host, float *y_host,
+                                  int mode, float *kernel_ms);
+
+/* ---- synthetic CSR of stated (rows, cols, nnz) ---------------------------
+ * Counter-based generator (DESIGN.md "Synthetic workloads"): element k of
+ * global row r is a pure function of (seed, r, k, row length, band), so the
+ * host can regenerate any row.  d_row_ptr (n_local+1 entries, rebased to 0)
+ * gives the lengths of global rows [row0, row0+n_local).  band = 0: columns
+ * uniform over [0, cols); band > 0: inside a diagonal band of that width. */
+SPMV_API int spmv_synth_fill(uint64_t seed, int64_t row0, int64_t n_local, int64_t rows, int64_t cols,
+                    int64_t band, const int32_t *d_row_ptr, int32_t *d_col_idx, float *d_vals,
+                    void *stream);
+SPMV_API int spmv_synth_x(uint64_t seed, int64_t j0, int64_t n, float *d_x, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_HIP_H */

@@ -1,0 +1,210 @@
+"""ctypes binding of include/spmv_hip.h (libspmv_hip.so).
+
+Every call goes to the HIP library; there is no Python or CPU implementation behind these
+wrappers.  A non-zero status raises :class:`SpmvError` with ``spmv_last_error()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "lib" / "libspmv_hip.so"
+LAUNCHERS_PATH = PKG_DIR / "lib" / "libspmv_launchers.so"
+TESTER_PATH = PKG_DIR / "bin" / "sparse_sgemv"
+
+# enum spmv_variant
+SCALAR, WAVE, WAVE_PIPE, VECTOR, ADAPTIVE, TILED = range(6)
+VARIANTS = {"scalar": SCALAR, "wave": WAVE, "wave_pipe": WAVE_PIPE, "vector": VECTOR,
+            "adaptive": ADAPTIVE, "tiled": TILED}
+
+# enum spmv_status
+OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_VARIANT, ERR_NOT_PLANNED = 0, -1, -2, -3, -4, -5
+
+# every symbol include/spmv_hip.h declares: name -> (restype, argtypes)
+_i32p, _f32p, _vp = C.c_void_p, C.c_void_p, C.c_void_p   # raw addresses (host or device)
+_H = C.c_void_p                                           # spmv_csr_t*
+_HP = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "spmv_device_count": (C.c_int, []),
+    "spmv_last_error": (C.c_char_p, []),
+    "spmv_variant_name": (C.c_char_p, [C.c_int]),
+    "spmv_csr_create_host": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, _i32p, _i32p, _f32p, _HP]),
+    "spmv_csr_create_device": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, _i32p, _i32p, _f32p, _HP]),
+    "spmv_csr_from_dense_host": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
+    "spmv_csr_from_dense_device": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
+    "spmv_csr_download": (C.c_int, [_H, _i32p, _i32p, _f32p]),
+    "spmv_csr_dims": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "spmv_csr_destroy": (C.c_int, [_H]),
+    "spmv_csr_plan": (C.c_int, [_H, C.c_int, _vp]),
+    "spmv_csr_run": (C.c_int, [_H, C.c_int, _f32p, _f32p, _vp]),
+    "spmv_csr_plan_bytes": (C.c_int64, [_H, C.c_int]),
+    "spmv_csr_time": (C.c_int, [_H, C.c_int, _f32p, _f32p, C.c_int, _vp, C.POINTER(C.c_float)]),
+    "spmv_csr_run_host": (C.c_int, [_H, C.c_int, _f32p, _f32p, C.POINTER(C.c_float)]),
+    "spmv_dense_gemv": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _vp]),
+    "spmv_dense_gemv_host": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.POINTER(C.c_float)]),
+    "spmv_synth_fill": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                  _i32p, _i32p, _f32p, _vp]),
+    "spmv_synth_x": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, _f32p, _vp]),
+}
+
+
+class SpmvError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libspmv_hip status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libspmv_hip.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C spmv-test_amd`); there is no fallback implementation")
+        # torch bundles its own libamdhip64.so.7; importing it first makes this library bind to
+        # the same HIP runtime instance, so torch device pointers and streams are valid here.
+        import torch  # noqa: F401
+        l = C.CDLL(os.fspath(LIB_PATH), mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != OK:
+        raise SpmvError(status, lib().spmv_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return lib().spmv_device_count()
+
+
+def _ptr(t) -> int:
+    """Address of a torch tensor / numpy array / None."""
+    if t is None:
+        return 0
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def _stream_handle(stream=None) -> int:
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream
+
+
+class CsrMatrix:
+    """Owner of one ``spmv_csr_t`` handle (a whole matrix or one row-block shard)."""
+
+    def __init__(self, handle: int, keepalive=()):
+        self._h = C.c_void_p(handle)
+        self._keep = tuple(keepalive)
+        r, c, z = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().spmv_csr_dims(self._h, C.byref(r), C.byref(c), C.byref(z)))
+        self.rows, self.cols, self.nnz = r.value, c.value, z.value
+
+    # -- constructors ---------------------------------------------------------
+    @classmethod
+    def from_host(cls, rows, cols, row_ptr, col_idx, vals):
+        import numpy as np
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        vals = np.ascontiguousarray(vals, dtype=np.float32)
+        h = C.c_void_p()
+        check(lib().spmv_csr_create_host(rows, cols, int(col_idx.size), _ptr(row_ptr), _ptr(col_idx),
+                                         _ptr(vals), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_device(cls, rows, cols, row_ptr, col_idx, vals):
+        """Borrow torch device tensors (int32, int32, float32); they are kept alive by this object."""
+        h = C.c_void_p()
+        check(lib().spmv_csr_create_device(rows, cols, int(col_idx.numel()), _ptr(row_ptr), _ptr(col_idx),
+                                           _ptr(vals), C.byref(h)))
+        return cls(h.value, keepalive=(row_ptr, col_idx, vals))
+
+    @classmethod
+    def from_dense_host(cls, A):
+        """Dense row-major numpy A[M][N] -> CSR of A^T on the device (matrix_csr.cpp:5-23 semantics)."""
+        import numpy as np
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        M, N = A.shape
+        h = C.c_void_p()
+        check(lib().spmv_csr_from_dense_host(M, N, _ptr(A), 0, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_dense_device(cls, A):
+        M, N = A.shape
+        h = C.c_void_p()
+        check(lib().spmv_csr_from_dense_device(M, N, _ptr(A), _stream_handle(), C.byref(h)))
+        return cls(h.value)
+
+    # -- hot path ---------------------------------------------------------------
+    def plan(self, variant: int, stream=None) -> None:
+        check(lib().spmv_csr_plan(self._h, variant, _stream_handle(stream)))
+
+    def run(self, variant: int, x, y, stream=None) -> None:
+        """Enqueue y = A x on torch's current stream (or ``stream``).  x, y: float32 device tensors."""
+        assert x.numel() >= self.cols and y.numel() >= self.rows
+        check(lib().spmv_csr_run(self._h, variant, _ptr(x), _ptr(y), _stream_handle(stream)))
+
+    def time(self, variant: int, x, y, iters: int, stream=None) -> float:
+        """Mean ms per launch over ``iters`` launches, HIP events on the launch stream."""
+        ms = C.c_float()
+        check(lib().spmv_csr_time(self._h, variant, _ptr(x), _ptr(y), iters, _stream_handle(stream),
+                                  C.byref(ms)))
+        return ms.value
+
+    def run_host(self, variant: int, x, y) -> float:
+        import numpy as np
+        assert x.dtype == np.float32 and y.dtype == np.float32
+        ms = C.c_float()
+        check(lib().spmv_csr_run_host(self._h, variant, _ptr(x), _ptr(y), C.byref(ms)))
+        return ms.value
+
+    def plan_bytes(self, variant: int) -> int:
+        return lib().spmv_csr_plan_bytes(self._h, variant)
+
+    def download(self):
+        import numpy as np
+        rp = np.empty(self.rows + 1, np.int32)
+        ci = np.empty(self.nnz, np.int32)
+        va = np.empty(self.nnz, np.float32)
+        check(lib().spmv_csr_download(self._h, _ptr(rp), _ptr(ci), _ptr(va)))
+        return rp, ci, va
+
+    def close(self) -> None:
+        if self._h:
+            check(lib().spmv_csr_destroy(self._h))
+            self._h = C.c_void_p()
+            self._keep = ()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dense_gemv(A, x, y, mode: int, stream=None) -> None:
+    M, N = A.shape
+    check(lib().spmv_dense_gemv(M, N, _ptr(A), _ptr(x), _ptr(y), mode, _stream_handle(stream)))
+
+
+def synth_fill(seed, row0, n_local, rows, cols, band, row_ptr, col_idx, vals, stream=None) -> None:
+    check(lib().spmv_synth_fill(seed, row0, n_local, rows, cols, band, _ptr(row_ptr), _ptr(col_idx),
+                                _ptr(vals), _stream_handle(stream)))
+
+
+def synth_x(seed, j0, n, x, stream=None) -> None:
+    check(lib().spmv_synth_x(seed, j0, n, _ptr(x), _stream_handle(stream)))

@@ -1,0 +1,384 @@
+// capi.hip -- the extern "C" entry points of include/spmv_hip.h.
+#include <cstdarg>
+#include <cstring>
+#include <new>
+#include "spmv_internal.hpp"
+
+namespace spmv {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %s:%d: %s (%s)", file, line, hipGetErrorString(e), what);
+    return SPMV_ERR_HIP;
+}
+
+static int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible (hipGetDeviceCount: %s); libspmv_hip has no CPU path",
+                  e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return SPMV_ERR_NO_DEVICE;
+    }
+    return SPMV_OK;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace spmv
+
+using namespace spmv;
+
+extern "C" {
+
+int spmv_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *spmv_last_error(void) { return g_err; }
+
+const char *spmv_variant_name(int variant)
+{
+    switch (variant) {
+        case SPMV_SCALAR: return "scalar";
+        case SPMV_WAVE: return "wave";
+        case SPMV_WAVE_PIPE: return "wave_pipe";
+        case SPMV_VECTOR: return "vector";
+        case SPMV_ADAPTIVE: return "adaptive";
+        case SPMV_TILED: return "tiled";
+        default: return "unknown";
+    }
+}
+
+static int check_dims(int64_t rows, int64_t cols, int64_t nnz)
+{
+    if (rows < 0 || cols < 0 || nnz < 0 || rows >= (1LL << 31) || cols >= (1LL << 31) || nnz >= (1LL << 31)) {
+        set_error("bad dimensions rows=%lld cols=%lld nnz=%lld (each must be in [0, 2^31))", (long long)rows,
+                  (long long)cols, (long long)nnz);
+        return SPMV_ERR_INVALID;
+    }
+    return SPMV_OK;
+}
+
+int spmv_csr_create_host(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
+                         const int32_t *col_idx, const float *vals, spmv_csr_t **out)
+{
+    if (!out || !row_ptr || (nnz > 0 && (!col_idx || !vals))) {
+        set_error("spmv_csr_create_host: null argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = check_dims(rows, cols, nnz);
+    if (rc) return rc;
+    if ((rc = require_device())) return rc;
+    if (row_ptr[0] != 0 || row_ptr[rows] != nnz) {
+        set_error("spmv_csr_create_host: row_ptr[0]=%d row_ptr[rows]=%d, expected 0 and nnz=%lld", row_ptr[0],
+                  row_ptr[rows], (long long)nnz);
+        return SPMV_ERR_INVALID;
+    }
+    int32_t *d_rp = nullptr, *d_ci = nullptr;
+    float *d_v = nullptr;
+    const size_t n1 = nnz > 0 ? (size_t)nnz : 1;
+    SPMV_HIP_TRY(hipMalloc((void **)&d_rp, sizeof(int32_t) * ((size_t)rows + 1)));
+    SPMV_HIP_TRY(hipMalloc((void **)&d_ci, sizeof(int32_t) * n1));
+    SPMV_HIP_TRY(hipMalloc((void **)&d_v, sizeof(float) * n1));
+    SPMV_HIP_TRY(hipMemcpy(d_rp, row_ptr, sizeof(int32_t) * ((size_t)rows + 1), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        SPMV_HIP_TRY(hipMemcpy(d_ci, col_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+        SPMV_HIP_TRY(hipMemcpy(d_v, vals, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    spmv_csr *h = new (std::nothrow) spmv_csr();
+    if (!h) { set_error("out of host memory"); return SPMV_ERR_INVALID; }
+    h->rows = rows; h->cols = cols; h->nnz = nnz;
+    h->d_row_ptr = d_rp; h->d_col_idx = d_ci; h->d_vals = d_v;
+    h->owns_arrays = true;
+    SPMV_HIP_TRY(hipGetDevice(&h->device));
+    *out = h;
+    return SPMV_OK;
+}
+
+int spmv_csr_create_device(int64_t rows, int64_t cols, int64_t nnz, const int32_t *d_row_ptr,
+                           const int32_t *d_col_idx, const float *d_vals, spmv_csr_t **out)
+{
+    if (!out || !d_row_ptr || (nnz > 0 && (!d_col_idx || !d_vals))) {
+        set_error("spmv_csr_create_device: null argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = check_dims(rows, cols, nnz);
+    if (rc) return rc;
+    if ((rc = require_device())) return rc;
+    if (!aligned16(d_col_idx) || !aligned16(d_vals)) {
+        set_error("spmv_csr_create_device: col_idx and vals must be 16-byte aligned");
+        return SPMV_ERR_INVALID;
+    }
+    spmv_csr *h = new (std::nothrow) spmv_csr();
+    if (!h) { set_error("out of host memory"); return SPMV_ERR_INVALID; }
+    h->rows = rows; h->cols = cols; h->nnz = nnz;
+    h->d_row_ptr = d_row_ptr; h->d_col_idx = d_col_idx; h->d_vals = d_vals;
+    h->owns_arrays = false;
+    SPMV_HIP_TRY(hipGetDevice(&h->device));
+    *out = h;
+    return SPMV_OK;
+}
+
+int spmv_csr_from_dense_device(int M, int N, const float *d_A, void *stream, spmv_csr_t **out)
+{
+    if (!out || M < 0 || N < 0 || (!d_A && (int64_t)M * N > 0)) {
+        set_error("spmv_csr_from_dense_device: bad argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return dense_to_csr(M, N, d_A, (hipStream_t)stream, out);
+}
+
+int spmv_csr_from_dense_host(int M, int N, const float *A_host, void *stream, spmv_csr_t **out)
+{
+    if (!out || M < 0 || N < 0 || (!A_host && (int64_t)M * N > 0)) {
+        set_error("spmv_csr_from_dense_host: bad argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    const size_t bytes = sizeof(float) * (size_t)M * (size_t)N;
+    float *d_A = nullptr;
+    SPMV_HIP_TRY(hipMalloc((void **)&d_A, bytes ? bytes : 4));
+    hipError_t e = hipMemcpyAsync(d_A, A_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipFree(d_A); return hip_fail(e, "hipMemcpyAsync(A)", __FILE__, __LINE__); }
+    rc = dense_to_csr(M, N, d_A, (hipStream_t)stream, out);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d_A);
+    return rc;
+}
+
+int spmv_csr_download(const spmv_csr_t *h, int32_t *row_ptr, int32_t *col_idx, float *vals)
+{
+    if (!h) { set_error("spmv_csr_download: null handle"); return SPMV_ERR_INVALID; }
+    if (row_ptr)
+        SPMV_HIP_TRY(hipMemcpy(row_ptr, h->d_row_ptr, sizeof(int32_t) * ((size_t)h->rows + 1), hipMemcpyDeviceToHost));
+    if (col_idx && h->nnz)
+        SPMV_HIP_TRY(hipMemcpy(col_idx, h->d_col_idx, sizeof(int32_t) * (size_t)h->nnz, hipMemcpyDeviceToHost));
+    if (vals && h->nnz)
+        SPMV_HIP_TRY(hipMemcpy(vals, h->d_vals, sizeof(float) * (size_t)h->nnz, hipMemcpyDeviceToHost));
+    return SPMV_OK;
+}
+
+int spmv_csr_dims(const spmv_csr_t *h, int64_t *rows, int64_t *cols, int64_t *nnz)
+{
+    if (!h) { set_error("spmv_csr_dims: null handle"); return SPMV_ERR_INVALID; }
+    if (rows) *rows = h->rows;
+    if (cols) *cols = h->cols;
+    if (nnz) *nnz = h->nnz;
+    return SPMV_OK;
+}
+
+int spmv_csr_destroy(spmv_csr_t *h)
+{
+    if (!h) return SPMV_OK;
+    int rc = SPMV_OK;
+    auto fr = [&](const void *p) {
+        if (p && hipFree(const_cast<void *>(p)) != hipSuccess) rc = SPMV_ERR_HIP;
+    };
+    if (h->owns_arrays) { fr(h->d_row_ptr); fr(h->d_col_idx); fr(h->d_vals); }
+    fr(h->d_chunk_lb); fr(h->d_carry); fr(h->d_chunk_win);
+    delete h;
+    if (rc) set_error("hipFree failed in spmv_csr_destroy");
+    return rc;
+}
+
+int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream)
+{
+    if (!h) { set_error("spmv_csr_plan: null handle"); return SPMV_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+        case SPMV_SCALAR:
+        case SPMV_WAVE:
+        case SPMV_WAVE_PIPE: return SPMV_OK;
+        case SPMV_VECTOR: return plan_vector(*h, s);
+        case SPMV_ADAPTIVE: return plan_adaptive(*h, false, s);
+        case SPMV_TILED: return plan_adaptive(*h, true, s);
+        default:
+            set_error("spmv_csr_plan: unknown variant %d", variant);
+            return SPMV_ERR_VARIANT;
+    }
+}
+
+int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void *stream)
+{
+    if (!h || (!d_x && h->cols > 0) || (!d_y && h->rows > 0)) {
+        set_error("spmv_csr_run: null argument");
+        return SPMV_ERR_INVALID;
+    }
+    if (!aligned16(d_x)) {
+        set_error("spmv_csr_run: x must be 16-byte aligned");
+        return SPMV_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+        case SPMV_SCALAR: return launch_scalar(*h, d_x, d_y, s);
+        case SPMV_WAVE: return launch_wave(*h, d_x, d_y, false, s);
+        case SPMV_WAVE_PIPE: return launch_wave(*h, d_x, d_y, true, s);
+        case SPMV_VECTOR: return launch_vector(*h, d_x, d_y, s);
+        case SPMV_ADAPTIVE: return launch_adaptive(*h, d_x, d_y, false, s);
+        case SPMV_TILED: return launch_adaptive(*h, d_x, d_y, true, s);
+        default:
+            set_error("spmv_csr_run: unknown variant %d", variant);
+            return SPMV_ERR_VARIANT;
+    }
+}
+
+int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
+{
+    if (!h) return 0;
+    switch (variant) {
+        case SPMV_ADAPTIVE: return (int64_t)(h->nchunks + 1) * 4 + (int64_t)h->nchunks * 8;  // lb + carry w/r
+        case SPMV_TILED: return (int64_t)(h->nchunks + 1) * 4 + (int64_t)h->nchunks * 16;
+        default: return 0;
+    }
+}
+
+int spmv_csr_time(spmv_csr_t *h, int variant, const float *d_x, float *d_y, int iters, void *stream,
+                  float *ms_per_launch)
+{
+    if (iters <= 0 || !ms_per_launch) { set_error("spmv_csr_time: bad argument"); return SPMV_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t t0, t1;
+    SPMV_HIP_TRY(hipEventCreate(&t0));
+    SPMV_HIP_TRY(hipEventCreate(&t1));
+    int rc = SPMV_OK;
+    SPMV_HIP_TRY(hipEventRecord(t0, s));
+    for (int i = 0; i < iters && rc == SPMV_OK; ++i) rc = spmv_csr_run(h, variant, d_x, d_y, s);
+    SPMV_HIP_TRY(hipEventRecord(t1, s));
+    SPMV_HIP_TRY(hipEventSynchronize(t1));
+    float ms = 0.0f;
+    SPMV_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    *ms_per_launch = ms / (float)iters;
+    return rc;
+}
+
+// RAII for the host-buffer conveniences
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+};
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+}  // namespace
+
+int spmv_csr_run_host(spmv_csr_t *h, int variant, const float *x_host, float *y_host, float *kernel_ms)
+{
+    if (!h || (!x_host && h->cols > 0) || (!y_host && h->rows > 0)) {
+        set_error("spmv_csr_run_host: null argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = spmv_csr_plan(h, variant, nullptr);
+    if (rc) return rc;
+    DevBuf dx, dy;
+    EventPair ev;
+    SPMV_HIP_TRY(dx.alloc(sizeof(float) * (size_t)h->cols));
+    SPMV_HIP_TRY(dy.alloc(sizeof(float) * (size_t)h->rows));
+    SPMV_HIP_TRY(hipMemcpy(dx.p, x_host, sizeof(float) * (size_t)h->cols, hipMemcpyHostToDevice));
+    SPMV_HIP_TRY(hipEventCreate(&ev.a));
+    SPMV_HIP_TRY(hipEventCreate(&ev.b));
+    SPMV_HIP_TRY(hipDeviceSynchronize());
+    SPMV_HIP_TRY(hipEventRecord(ev.a, nullptr));
+    rc = spmv_csr_run(h, variant, (const float *)dx.p, (float *)dy.p, nullptr);
+    SPMV_HIP_TRY(hipEventRecord(ev.b, nullptr));
+    SPMV_HIP_TRY(hipEventSynchronize(ev.b));
+    if (rc) return rc;
+    float ms = 0.0f;
+    SPMV_HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+    if (kernel_ms) *kernel_ms = ms;
+    SPMV_HIP_TRY(hipDeviceSynchronize());
+    SPMV_HIP_TRY(hipMemcpy(y_host, dy.p, sizeof(float) * (size_t)h->rows, hipMemcpyDeviceToHost));
+    return SPMV_OK;
+}
+
+int spmv_dense_gemv_host(int M, int N, const float *A_host, const float *x_host, float *y_host, int mode,
+                         float *kernel_ms)
+{
+    if (M < 0 || N < 0 || ((int64_t)M * N > 0 && (!A_host || !x_host)) || (N > 0 && !y_host)) {
+        set_error("spmv_dense_gemv_host: bad argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    DevBuf dA, dx, dy;
+    EventPair ev;
+    SPMV_HIP_TRY(dA.alloc(sizeof(float) * (size_t)M * (size_t)N));
+    SPMV_HIP_TRY(dx.alloc(sizeof(float) * (size_t)M));
+    SPMV_HIP_TRY(dy.alloc(sizeof(float) * (size_t)N));
+    SPMV_HIP_TRY(hipMemcpy(dA.p, A_host, sizeof(float) * (size_t)M * (size_t)N, hipMemcpyHostToDevice));
+    SPMV_HIP_TRY(hipMemcpy(dx.p, x_host, sizeof(float) * (size_t)M, hipMemcpyHostToDevice));
+    SPMV_HIP_TRY(hipEventCreate(&ev.a));
+    SPMV_HIP_TRY(hipEventCreate(&ev.b));
+    SPMV_HIP_TRY(hipDeviceSynchronize());
+    SPMV_HIP_TRY(hipEventRecord(ev.a, nullptr));
+    rc = dense_gemv(M, N, (const float *)dA.p, (const float *)dx.p, (float *)dy.p, mode, nullptr);
+    SPMV_HIP_TRY(hipEventRecord(ev.b, nullptr));
+    SPMV_HIP_TRY(hipEventSynchronize(ev.b));
+    if (rc) return rc;
+    float ms = 0.0f;
+    SPMV_HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+    if (kernel_ms) *kernel_ms = ms;
+    SPMV_HIP_TRY(hipDeviceSynchronize());
+    SPMV_HIP_TRY(hipMemcpy(y_host, dy.p, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost));
+    return SPMV_OK;
+}
+
+int spmv_dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, void *stream)
+{
+    if (M < 0 || N < 0 || ((int64_t)M * N > 0 && (!d_A || !d_x)) || (N > 0 && !d_y)) {
+        set_error("spmv_dense_gemv: bad argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return dense_gemv(M, N, d_A, d_x, d_y, mode, (hipStream_t)stream);
+}
+
+int spmv_synth_fill(uint64_t seed, int64_t row0, int64_t n_local, int64_t rows, int64_t cols, int64_t band,
+                    const int32_t *d_row_ptr, int32_t *d_col_idx, float *d_vals, void *stream)
+{
+    if (n_local < 0 || row0 < 0 || row0 + n_local > rows || cols <= 0 || cols >= (1LL << 31) ||
+        rows >= (1LL << 31) || !d_row_ptr) {
+        set_error("spmv_synth_fill: bad argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return synth_fill(seed, row0, n_local, rows, cols, band, d_row_ptr, d_col_idx, d_vals, (hipStream_t)stream);
+}
+
+int spmv_synth_x(uint64_t seed, int64_t j0, int64_t n, float *d_x, void *stream)
+{
+    if (n < 0 || j0 < 0 || (n > 0 && !d_x)) { set_error("spmv_synth_x: bad argument"); return SPMV_ERR_INVALID; }
+    int rc = require_device();
+    if (rc) return rc;
+    return synth_x(seed, j0, n, d_x, (hipStream_t)stream);
+}
+
+}  // extern "C"

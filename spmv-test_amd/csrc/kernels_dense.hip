@@ -1,0 +1,239 @@
+// kernels_dense.hip -- the dense side of the boundary.
+//
+//   dense_to_csr   device-side replacement of CSRMatrix::CSRMatrix
+//                  (/root/reference/src/matrix_csr.cpp:5-23): dense row-major A[M][N] -> CSR of
+//                  A^T; an element is kept iff (v != 0.0f) (-0.0f dropped, NaN kept, :15);
+//                  column indices ascend inside a row (:12-20).  The reference does this as a
+//                  single-threaded stride-N host scan (0.69 s at 4096^2); here it is a
+//                  count / scan / fill over (column, row-slab) pairs with coalesced reads.
+//   dense_gemv     y[i] = sum_j x[j]*A[j*N+i]: the dense slots of the launcher API --
+//                  naive_kernel (naive.cu:4-11), tiling_kernel (tiling_smem.cu:4-32) and the
+//                  vendor slot cublas_gemv_gpu (cublas.cu:4-44).
+#include "spmv_internal.hpp"
+
+namespace spmv {
+
+constexpr int kSlabs = 64;  // row slabs of A processed in parallel per output column
+
+__device__ __forceinline__ void slab_range(int M, int s, int &j0, int &j1)
+{
+    const int per = (M + kSlabs - 1) / kSlabs;
+    j0 = s * per;
+    j1 = j0 + per;
+    if (j0 > M) j0 = M;
+    if (j1 > M) j1 = M;
+}
+
+// counts[i*kSlabs + s] = nonzeros of column i inside slab s
+__global__ __launch_bounds__(kBlock) void k_dense_count(int M, int N, const float *__restrict__ A,
+                                                        int32_t *__restrict__ counts)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i >= N) return;
+    int j0, j1;
+    slab_range(M, s, j0, j1);
+    int cnt = 0;
+    for (int j = j0; j < j1; ++j) cnt += (A[(size_t)j * N + i] != 0.0f) ? 1 : 0;
+    counts[(size_t)i * kSlabs + s] = cnt;
+}
+
+// In-place exclusive scan of n int32 by one 1024-thread workgroup; total -> *total_out.
+__global__ __launch_bounds__(1024) void k_exclusive_scan(int64_t n, int32_t *__restrict__ data,
+                                                         int32_t *__restrict__ total_out)
+{
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = t * per, e = (b + per < n) ? b + per : n;
+    int64_t sum = 0;
+    for (int64_t k = b; k < e; ++k) sum += data[k];
+    part[t] = sum;
+    __syncthreads();
+    // Hillis-Steele over 1024 partials
+    for (int o = 1; o < 1024; o <<= 1) {
+        int64_t v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int64_t run = (t == 0) ? 0 : part[t - 1];
+    for (int64_t k = b; k < e; ++k) {
+        int32_t v = data[k];
+        data[k] = (int32_t)run;
+        run += v;
+    }
+    if (t == 1023) *total_out = (int32_t)part[1023];
+}
+
+// row_ptr[i] = offs[i*kSlabs] for i < N, row_ptr[N] = nnz
+__global__ void k_row_ptr_from_offsets(int N, const int32_t *__restrict__ offs, const int32_t *__restrict__ total,
+                                       int32_t *__restrict__ row_ptr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) row_ptr[i] = offs[(size_t)i * kSlabs];
+    else if (i == N) row_ptr[N] = *total;
+}
+
+__global__ __launch_bounds__(kBlock) void k_dense_fill(int M, int N, const float *__restrict__ A,
+                                                       const int32_t *__restrict__ offs,
+                                                       int32_t *__restrict__ col_idx, float *__restrict__ vals)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i >= N) return;
+    int j0, j1;
+    slab_range(M, s, j0, j1);
+    int32_t p = offs[(size_t)i * kSlabs + s];
+    for (int j = j0; j < j1; ++j) {
+        const float v = A[(size_t)j * N + i];
+        if (v != 0.0f) {
+            vals[p] = v;
+            col_idx[p] = j;
+            ++p;
+        }
+    }
+}
+
+static int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, what, __FILE__, __LINE__);
+    return SPMV_OK;
+}
+
+int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out)
+{
+    int rc;
+    int32_t *d_counts = nullptr, *d_total = nullptr, *d_row_ptr = nullptr, *d_col = nullptr;
+    float *d_val = nullptr;
+    const size_t ncnt = (size_t)N * kSlabs;
+    SPMV_HIP_TRY(hipMalloc((void **)&d_counts, sizeof(int32_t) * (ncnt ? ncnt : 1)));
+    SPMV_HIP_TRY(hipMalloc((void **)&d_total, sizeof(int32_t)));
+    SPMV_HIP_TRY(hipMalloc((void **)&d_row_ptr, sizeof(int32_t) * ((size_t)N + 1)));
+    SPMV_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(int32_t), s));
+    const dim3 grid((N + kBlock - 1) / kBlock ? (N + kBlock - 1) / kBlock : 1, kSlabs);
+    if (N > 0) {
+        hipLaunchKernelGGL(k_dense_count, grid, dim3(kBlock), 0, s, M, N, d_A, d_counts);
+        if ((rc = check_launch("k_dense_count"))) return rc;
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, (int64_t)ncnt, d_counts, d_total);
+        if ((rc = check_launch("k_exclusive_scan"))) return rc;
+    }
+    hipLaunchKernelGGL(k_row_ptr_from_offsets, dim3((N + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, N,
+                       d_counts, d_total, d_row_ptr);
+    if ((rc = check_launch("k_row_ptr_from_offsets"))) return rc;
+    int32_t nnz = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&nnz, d_total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    SPMV_HIP_TRY(hipMalloc((void **)&d_col, sizeof(int32_t) * ((size_t)nnz ? (size_t)nnz : 1)));
+    SPMV_HIP_TRY(hipMalloc((void **)&d_val, sizeof(float) * ((size_t)nnz ? (size_t)nnz : 1)));
+    if (N > 0 && nnz > 0) {
+        hipLaunchKernelGGL(k_dense_fill, grid, dim3(kBlock), 0, s, M, N, d_A, d_counts, d_col, d_val);
+        if ((rc = check_launch("k_dense_fill"))) return rc;
+    }
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    SPMV_HIP_TRY(hipFree(d_counts));
+    SPMV_HIP_TRY(hipFree(d_total));
+
+    spmv_csr *h = new spmv_csr();
+    h->rows = N;
+    h->cols = M;
+    h->nnz = nnz;
+    h->d_row_ptr = d_row_ptr;
+    h->d_col_idx = d_col;
+    h->d_vals = d_val;
+    h->owns_arrays = true;
+    SPMV_HIP_TRY(hipGetDevice(&h->device));
+    *out = h;
+    return SPMV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// mode 0: thread per output, j ascending, unfused -> bit-identical to SgemvCPU (tester.cpp:36-45)
+__global__ __launch_bounds__(kBlock) void k_gemv_naive(int M, int N, const float *__restrict__ A,
+                                                       const float *__restrict__ x, float *__restrict__ y)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    float acc = 0.0f;
+    for (int j = 0; j < M; ++j) acc = __fadd_rn(acc, __fmul_rn(x[j], A[(size_t)j * N + i]));
+    y[i] = acc;
+}
+
+// mode 1: same order, x staged through LDS 1024 entries at a time
+__global__ __launch_bounds__(kBlock) void k_gemv_xtile(int M, int N, const float *__restrict__ A,
+                                                       const float *__restrict__ x, float *__restrict__ y)
+{
+    __shared__ float xs[1024];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    float acc = 0.0f;
+    for (int jb = 0; jb < M; jb += 1024) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 1024; t += kBlock) xs[t] = (jb + t < M) ? x[jb + t] : 0.0f;
+        __syncthreads();
+        const int jn = (M - jb) < 1024 ? (M - jb) : 1024;
+        if (i < N)
+            for (int j = 0; j < jn; ++j) acc = __fadd_rn(acc, __fmul_rn(xs[j], A[(size_t)(jb + j) * N + i]));
+    }
+    if (i < N) y[i] = acc;
+}
+
+// mode 2: rows of A split into kSlabs slabs -> N/256 x kSlabs workgroups stream A with
+// coalesced 256-B-per-wave rows; per-slab partials are combined in slab order.
+__global__ __launch_bounds__(kBlock) void k_gemv_split(int M, int N, const float *__restrict__ A,
+                                                       const float *__restrict__ x, float *__restrict__ part)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i >= N) return;
+    int j0, j1;
+    slab_range(M, s, j0, j1);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int j = j0;
+    for (; j + 3 < j1; j += 4) {
+        a0 = fmaf(x[j], A[(size_t)j * N + i], a0);
+        a1 = fmaf(x[j + 1], A[(size_t)(j + 1) * N + i], a1);
+        a2 = fmaf(x[j + 2], A[(size_t)(j + 2) * N + i], a2);
+        a3 = fmaf(x[j + 3], A[(size_t)(j + 3) * N + i], a3);
+    }
+    for (; j < j1; ++j) a0 = fmaf(x[j], A[(size_t)j * N + i], a0);
+    part[(size_t)s * N + i] = (a0 + a1) + (a2 + a3);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gemv_combine(int N, const float *__restrict__ part, float *__restrict__ y)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    float acc = 0.0f;
+    for (int s = 0; s < kSlabs; ++s) acc += part[(size_t)s * N + i];
+    y[i] = acc;
+}
+
+int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s)
+{
+    if (N == 0) return SPMV_OK;
+    const int blocks = (N + kBlock - 1) / kBlock;
+    int rc;
+    if (mode == 0) {
+        hipLaunchKernelGGL(k_gemv_naive, dim3(blocks), dim3(kBlock), 0, s, M, N, d_A, d_x, d_y);
+        return check_launch("k_gemv_naive");
+    }
+    if (mode == 1) {
+        hipLaunchKernelGGL(k_gemv_xtile, dim3(blocks), dim3(kBlock), 0, s, M, N, d_A, d_x, d_y);
+        return check_launch("k_gemv_xtile");
+    }
+    if (mode == 2) {
+        float *d_part = nullptr;
+        SPMV_HIP_TRY(hipMallocAsync((void **)&d_part, sizeof(float) * (size_t)kSlabs * N, s));
+        hipLaunchKernelGGL(k_gemv_split, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, d_part);
+        if ((rc = check_launch("k_gemv_split"))) return rc;
+        hipLaunchKernelGGL(k_gemv_combine, dim3(blocks), dim3(kBlock), 0, s, N, d_part, d_y);
+        if ((rc = check_launch("k_gemv_combine"))) return rc;
+        SPMV_HIP_TRY(hipFreeAsync(d_part, s));
+        return SPMV_OK;
+    }
+    set_error("spmv_dense_gemv: unknown mode %d", mode);
+    return SPMV_ERR_VARIANT;
+}
+
+}  // namespace spmv

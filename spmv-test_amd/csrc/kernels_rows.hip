@@ -1,0 +1,175 @@
+// kernels_rows.hip -- row-mapped CSR SpMV kernels for gfx950 (wave64).
+//
+//   k_scalar   thread per row, sequential, unfused mul+add
+//              role of csr_naive_kernel (/root/reference/src/kernels/csr_naive.cu:6-23);
+//              the same per-row operation order as SgemvCPU (src/tester.cpp:36-45),
+//              so results are bit-identical to the CPU oracle.
+//   k_wave     one 64-lane wavefront per row, lanes stride the row, __shfl_down tree
+//              role of wsp_kernel_v0/v1 (src/kernels/wsp.cu:4-56, 59-138): "one warp per
+//              output, butterfly reduce, lane 0 stores" -- re-derived for CSR and 64 lanes.
+//   k_vector   G-lane groups per row (G = 2..32), the short-row member of the family
+//              role of asp_kernel_v* (src/kernels/asp.cu:6-211: many outputs per block).
+//
+// All three are HBM/gather bound: no LDS, no MFMA (0.25 flop/byte).
+#include "spmv_internal.hpp"
+
+namespace spmv {
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_scalar(int64_t rows, const int32_t *__restrict__ row_ptr,
+                                                   const int32_t *__restrict__ col_idx,
+                                                   const float *__restrict__ vals,
+                                                   const float *__restrict__ x, float *__restrict__ y)
+{
+    int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= rows) return;
+    int32_t b = row_ptr[r], e = row_ptr[r + 1];
+    float acc = 0.0f;
+    for (int32_t k = b; k < e; ++k) {
+        // two roundings, like the host loop (no fma contraction)
+        acc = __fadd_rn(acc, __fmul_rn(x[col_idx[k]], vals[k]));
+    }
+    y[r] = acc;
+}
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_reduce_sum(float v)
+{
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;  // lane 0 holds the total
+}
+
+template <bool PIPE>
+__global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__restrict__ row_ptr,
+                                                 const int32_t *__restrict__ col_idx,
+                                                 const float *__restrict__ vals,
+                                                 const float *__restrict__ x, float *__restrict__ y)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (r >= rows) return;  // wave-uniform
+    const int32_t b = row_ptr[r], e = row_ptr[r + 1];
+    float acc = 0.0f;
+    int32_t k = b + lane;
+    if (PIPE) {
+        // four independent 64-wide slices in flight per trip: 8 streamed loads then
+        // 4 gathers are issued before the first use.
+        float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (; k + 3 * kWave < e; k += 4 * kWave) {
+            int32_t c0 = col_idx[k], c1 = col_idx[k + kWave], c2 = col_idx[k + 2 * kWave],
+                    c3 = col_idx[k + 3 * kWave];
+            float v0 = vals[k], v1 = vals[k + kWave], v2 = vals[k + 2 * kWave], v3 = vals[k + 3 * kWave];
+            float x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+            acc = fmaf(v0, x0, acc);
+            a1 = fmaf(v1, x1, a1);
+            a2 = fmaf(v2, x2, a2);
+            a3 = fmaf(v3, x3, a3);
+        }
+        acc = (acc + a1) + (a2 + a3);
+    }
+    for (; k < e; k += kWave) acc = fmaf(vals[k], x[col_idx[k]], acc);
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) y[r] = acc;
+}
+
+// ---------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_vector(int64_t rows, const int32_t *__restrict__ row_ptr,
+                                                   const int32_t *__restrict__ col_idx,
+                                                   const float *__restrict__ vals,
+                                                   const float *__restrict__ x, float *__restrict__ y)
+{
+    constexpr int kRowsPerBlock = kBlock / G;
+    const int sub = threadIdx.x % G;
+    const int64_t r = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x / G;
+    float acc = 0.0f;
+    if (r < rows) {
+        const int32_t b = row_ptr[r], e = row_ptr[r + 1];
+        for (int32_t k = b + sub; k < e; k += G) acc = fmaf(vals[k], x[col_idx[k]], acc);
+    }
+    // all 64 lanes take part in the shuffles (rows past the end carry zeros)
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, G);
+    if (sub == 0 && r < rows) y[r] = acc;
+}
+
+// ---------------------------------------------------------------------------
+static int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, what, __FILE__, __LINE__);
+    return SPMV_OK;
+}
+
+static bool grid_ok(int64_t blocks)
+{
+    if (blocks > 0x7fffffffLL) {
+        set_error("grid of %lld blocks exceeds the launch limit", (long long)blocks);
+        return false;
+    }
+    return true;
+}
+
+int launch_scalar(const spmv_csr &h, const float *x, float *y, hipStream_t s)
+{
+    if (h.rows == 0) return SPMV_OK;
+    int64_t blocks = (h.rows + kBlock - 1) / kBlock;
+    if (!grid_ok(blocks)) return SPMV_ERR_INVALID;
+    hipLaunchKernelGGL(k_scalar, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
+                       h.d_col_idx, h.d_vals, x, y);
+    return check_launch("k_scalar");
+}
+
+int launch_wave(const spmv_csr &h, const float *x, float *y, bool pipelined, hipStream_t s)
+{
+    if (h.rows == 0) return SPMV_OK;
+    constexpr int kRowsPerBlock = kBlock / kWave;
+    int64_t blocks = (h.rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (!grid_ok(blocks)) return SPMV_ERR_INVALID;
+    if (pipelined)
+        hipLaunchKernelGGL(k_wave<true>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
+                           h.d_col_idx, h.d_vals, x, y);
+    else
+        hipLaunchKernelGGL(k_wave<false>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
+                           h.d_col_idx, h.d_vals, x, y);
+    return check_launch("k_wave");
+}
+
+int plan_vector(spmv_csr &h, hipStream_t)
+{
+    // lanes per row = smallest power of two >= mean row length, in [2, 32]
+    double mean = h.rows > 0 ? (double)h.nnz / (double)h.rows : 0.0;
+    int g = 2;
+    while (g < 32 && (double)g < mean) g <<= 1;
+    h.vector_width = g;
+    return SPMV_OK;
+}
+
+template <int G>
+static int launch_vector_g(const spmv_csr &h, const float *x, float *y, hipStream_t s)
+{
+    constexpr int kRowsPerBlock = kBlock / G;
+    int64_t blocks = (h.rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (!grid_ok(blocks)) return SPMV_ERR_INVALID;
+    hipLaunchKernelGGL(k_vector<G>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
+                       h.d_col_idx, h.d_vals, x, y);
+    return check_launch("k_vector");
+}
+
+int launch_vector(const spmv_csr &h, const float *x, float *y, hipStream_t s)
+{
+    if (h.rows == 0) return SPMV_OK;
+    switch (h.vector_width) {
+        case 2: return launch_vector_g<2>(h, x, y, s);
+        case 4: return launch_vector_g<4>(h, x, y, s);
+        case 8: return launch_vector_g<8>(h, x, y, s);
+        case 16: return launch_vector_g<16>(h, x, y, s);
+        case 32: return launch_vector_g<32>(h, x, y, s);
+        default:
+            set_error("SPMV_VECTOR used before spmv_csr_plan");
+            return SPMV_ERR_NOT_PLANNED;
+    }
+}
+
+}  // namespace spmv

@@ -1,0 +1,71 @@
+// spmv_internal.hpp -- shared declarations of libspmv_hip.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include "spmv_hip.h"
+
+namespace spmv {
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define SPMV_HIP_TRY(call)                                                   \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return ::spmv::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// ---- geometry constants ----------------------------------------------------
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kBlock = 256;        // 4 waves: one per SIMD of a CU
+constexpr int kXcds = 8;           // MI355X: 8 XCDs, blocks dealt round-robin over them
+
+// ADAPTIVE / TILED chunking: every workgroup streams kChunk consecutive
+// nonzeros (col_idx + vals = 8 B each) with 16-byte loads per lane.
+constexpr int kNnzPerThread = 16;
+constexpr int kChunk = kBlock * kNnzPerThread;     // 4096 nnz = 32 KiB of stream per workgroup
+constexpr int kShortSeg = 32;                      // row segments up to this long: one lane sums them
+constexpr int kTileMaxCols = 8192;                 // TILED: widest x window staged in LDS (32 KiB)
+
+}  // namespace spmv
+
+// The opaque handle of include/spmv_hip.h.
+struct spmv_csr {
+    int64_t rows = 0, cols = 0, nnz = 0;
+    const int32_t *d_row_ptr = nullptr;
+    const int32_t *d_col_idx = nullptr;
+    const float *d_vals = nullptr;
+    bool owns_arrays = false;
+    int device = 0;
+
+    // plan state
+    int vector_width = 0;          // SPMV_VECTOR: lanes per row (2..64), 0 = not planned
+    int nchunks = 0;               // ADAPTIVE/TILED: ceil(nnz / kChunk)
+    int32_t *d_chunk_lb = nullptr; // [nchunks+1] first row whose row_ptr >= c*kChunk
+    float *d_carry = nullptr;      // [nchunks]   partial sum of the row continued from chunk c-1
+    int32_t *d_chunk_win = nullptr;// [2*nchunks] TILED: min column, window length (0 = too wide)
+    bool planned_adaptive = false;
+    bool planned_tiled = false;
+};
+
+namespace spmv {
+
+// ---- kernel launchers (each enqueues on `s`, returns a status) -------------
+int launch_scalar(const spmv_csr &h, const float *x, float *y, hipStream_t s);
+int launch_wave(const spmv_csr &h, const float *x, float *y, bool pipelined, hipStream_t s);
+int launch_vector(const spmv_csr &h, const float *x, float *y, hipStream_t s);
+int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s);
+
+int plan_vector(spmv_csr &h, hipStream_t s);
+int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s);
+
+int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out);
+int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s);
+
+int synth_fill(uint64_t seed, int64_t row0, int64_t n_local, int64_t rows, int64_t cols, int64_t band,
+               const int32_t *d_row_ptr, int32_t *d_col_idx, float *d_vals, hipStream_t s);
+int synth_x(uint64_t seed, int64_t j0, int64_t n, float *d_x, hipStream_t s);
+
+}  // namespace spmv

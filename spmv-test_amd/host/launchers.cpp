@@ -1,0 +1,67 @@
+// launchers.cpp -- the ten *_gemv_gpu launchers of include/kernel.hpp on top of the C ABI.
+//
+// Each follows the canonical shape of a reference launcher (e.g.
+// /root/reference/src/kernels/csr_naive.cu:26-76): build the sparse format from the dense
+// host matrix, move data to the device, run ONE timed kernel, copy Y back, release
+// everything.  What changed underneath: the format is always CSR and is built on the device
+// (spmv_csr_from_dense_host), and the kernel is one of the gfx950 variants of spmv_hip.h.
+#include "kernel.hpp"
+
+namespace {
+
+void run_csr(int M, int N, float *A_host, float *X_host, float *Y_host, int variant)
+{
+    spmv_csr_t *csr = nullptr;
+    SPMV_CHECK(spmv_csr_from_dense_host(M, N, A_host, nullptr, &csr));
+    float ms = 0.0f;
+    TIME_KERNEL(spmv_csr_run_host(csr, variant, X_host, Y_host, &ms), ms);
+    SPMV_CHECK(spmv_csr_destroy(csr));
+}
+
+void run_dense(int M, int N, float *A_host, float *X_host, float *Y_host, int mode)
+{
+    float ms = 0.0f;
+    TIME_KERNEL(spmv_dense_gemv_host(M, N, A_host, X_host, Y_host, mode, &ms), ms);
+}
+
+[[noreturn]] void bad_version(const char *name, int version)
+{
+    fprintf(stderr, "HIP error %s: unknown version %d\n", name, version);
+    exit(EXIT_FAILURE);
+}
+
+}  // namespace
+
+void naive_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_dense(M, N, A_host, X_host, Y_host, 0); }
+void tiling_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_dense(M, N, A_host, X_host, Y_host, 1); }
+void cublas_gemv_gpu(int M, int N, float *A, float *X, float *Y) { run_dense(M, N, A, X, Y, 2); }
+
+void csr_naive_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_csr(M, N, A_host, X_host, Y_host, SPMV_SCALAR); }
+void csr_tiling_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_csr(M, N, A_host, X_host, Y_host, SPMV_TILED); }
+void wsp_sm_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_csr(M, N, A_host, X_host, Y_host, SPMV_TILED); }
+void awsp_ref_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_csr(M, N, A_host, X_host, Y_host, SPMV_SCALAR); }
+
+void wsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version)
+{
+    switch (version) {
+        case 0: run_csr(M, N, A_host, X_host, Y_host, SPMV_WAVE); break;
+        case 1: run_csr(M, N, A_host, X_host, Y_host, SPMV_WAVE_PIPE); break;
+        default: bad_version("wsp_gemv_gpu", version);
+    }
+}
+
+void asp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version)
+{
+    if (version < 0 || version > 2) bad_version("asp_gemv_gpu", version);
+    run_csr(M, N, A_host, X_host, Y_host, SPMV_VECTOR);
+}
+
+void awsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version)
+{
+    switch (version) {
+        case 0:
+        case 1: run_csr(M, N, A_host, X_host, Y_host, SPMV_ADAPTIVE); break;
+        case 2: run_csr(M, N, A_host, X_host, Y_host, SPMV_TILED); break;
+        default: bad_version("awsp_gemv_gpu", version);
+    }
+}
