@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- fp32 CSR SpMV throughput on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the hot path over the synthetic matrix: y = A x through the C ABI
+(spmv_csr_run, all launches on torch's current stream); with N > 1 ranks the step also
+concatenates the output slices on every rank with one RCCL all-gather (BASELINE north_star).
+
+  N = 1   config 4 of BASELINE.json: 16Mi x 16Mi, 256Mi nnz, mixed row lengths (the config the
+          metric/target is quoted on); inputs resident in HBM before the timed region.
+  N > 1   config 5 generalised: (N*16Mi)^2, one 16Mi-row / 256Mi-nnz block per rank (weak
+          scaling: per-GPU work fixed), x (N*64 MiB) on every rank, y all-gathered every step.
+
+value      = algorithmic bytes of all ranks x K / wall time of the K timed steps  [GB/s]
+roofline   = algorithmic bytes of one launch / mean launch time by HIP events on the launch stream
+cpu_baseline = the CPU oracle (oracle/, checker code) walking a bounded row sample of the same
+             matrix on the host cores, timed in the same run; a baseline, not a target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--variant", default=os.environ.get("SPMV_BENCH_VARIANT", "adaptive"))
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"], help="N=1 workload (default: c4)")
+    ap.add_argument("--band", type=int, default=int(os.environ.get("SPMV_BENCH_BAND", "0")),
+                    help="0 = uniform columns (default), >0 = diagonal band of that many columns")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 21)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    pkg = ge.load_package()
+    capi, W = pkg.capi, pkg.workloads
+    if capi.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: libspmv_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    variant = capi.VARIANTS[args.variant]
+
+    # ---- the workload: this rank's row block, generated on the device ---------------------------
+    if world == 1:
+        w = W.config(args.config, band=args.band)
+        r0, r1 = 0, w.rows
+    else:
+        w = W.c5(world, band=args.band)
+        r0, r1 = rank * (w.rows // world), (rank + 1) * (w.rows // world)
+    t_setup = time.perf_counter()
+    rp = W.row_ptr(w, r0, r1 - r0)
+    nnz_local = int(rp[-1])
+    d_rp = torch.from_numpy(rp).to(dev)
+    d_ci = torch.empty(nnz_local, dtype=torch.int32, device=dev)
+    d_va = torch.empty(nnz_local, dtype=torch.float32, device=dev)
+    capi.synth_fill(w.seed, r0, r1 - r0, w.rows, w.cols, w.band, d_rp, d_ci, d_va)
+    A = capi.CsrMatrix.from_device(r1 - r0, w.cols, d_rp, d_ci, d_va)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    A.plan(variant)
+    ev1.record()
+    torch.cuda.synchronize()
+    plan_ms = ev0.elapsed_time(ev1)
+
+    if world == 1:
+        d_x = torch.empty(w.cols, dtype=torch.float32, device=dev)
+        capi.synth_x(w.seed, 0, w.cols, d_x)
+        d_y = torch.empty(r1 - r0, dtype=torch.float32, device=dev)
+
+        def step():
+            A.run(variant, d_x, d_y)
+        sh = None
+    else:
+        bounds = [p * (w.rows // world) for p in range(world + 1)]
+        sh = pkg.dist.ShardedSpmv(bounds, w.cols, lambda x, y: A.run(variant, x, y), dev)
+        if rank == 0:
+            capi.synth_x(w.seed, 0, w.cols, sh.x)
+        sh.broadcast_x(0)                    # the one-off distribution of the dense vector
+        d_x, d_y = sh.x, sh.y_local
+        step = sh.step
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warm-up, then EXACTLY K timed steps between barrier + synchronize ------------------------
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    step_ms_events = ev0.elapsed_time(ev1) / args.steps        # HIP events on the launch stream
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    bytes_rank = W.algorithmic_bytes(r1 - r0, w.cols, nnz_local)     # per launch, per rank
+    bytes_all = bytes_rank * world
+    value = bytes_all * args.steps / elapsed / 1e9
+    gflops = 2.0 * nnz_local * world * args.steps / elapsed / 1e9
+
+    # ---- the kernel alone (no collective): mean launch time by HIP events on its stream -----------
+    kernel_ms = A.time(variant, d_x, d_y, max(10, args.steps))
+    achieved = bytes_rank / (kernel_ms * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"       # written from the rocprofv3 --pmc passes
+        if tfile.exists():
+            try:
+                tj = json.loads(tfile.read_text())
+                key = f"{args.variant}:{w.name}:band{w.band}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "fp32 CSR SpMV achieved HBM bandwidth (algorithmic bytes / time)",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": w.describe(), "variant": args.variant,
+                       "rows_per_gpu": r1 - r0, "nnz_per_gpu": nnz_local,
+                       "parallelism": "single GPU" if world == 1 else f"row-block x{world}, all-gather(y) per step",
+                       "algorithmic_bytes_per_gpu": bytes_rank},
+            "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBS, 2),
+            "gflops": round(gflops, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_adaptive" if args.variant in ("adaptive", "tiled") else f"k_{args.variant}",
+                         "kernel_ms": round(kernel_ms, 5), "timing": "HIP events on the launch stream"},
+            "step_ms_events": round(step_ms_events, 5), "plan_ms": round(plan_ms, 4),
+            "plan_bytes": A.plan_bytes(variant), "setup_s": round(setup_s, 2),
+        }
+
+    # ---- CPU baseline: rank 0, N = 1 only, bounded sample of the same matrix ------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        orc = ge.load_oracle()
+        n = min(args.cpu_sample_rows, r1 - r0)
+        s0 = ((r1 - r0) // 3 // W.BLOCK_ROWS) * W.BLOCK_ROWS       # a window from the middle of the matrix
+        s1 = s0 + n
+        k0, k1 = int(rp[s0]), int(rp[s1])
+        rps = (rp[s0:s1 + 1].astype(np.int64) - k0).astype(np.int32)
+        ci = d_ci[k0:k1].cpu().numpy()
+        va = d_va[k0:k1].cpu().numpy()
+        x = d_x.cpu().numpy()
+        cores = os.cpu_count() or 1
+        y_cpu = orc.spmv(rps, ci, va, x, threads=cores)            # untimed first touch
+        reps, t_cpu = 0, 0.0
+        while t_cpu < 8.0 and reps < 200:
+            t1 = time.perf_counter()
+            y_cpu = orc.spmv(rps, ci, va, x, threads=cores)
+            t_cpu += time.perf_counter() - t1
+            reps += 1
+        b_sample = W.algorithmic_bytes(n, w.cols, k1 - k0)
+        out["cpu_baseline"] = {"value": round(b_sample * reps / t_cpu / 1e9, 3), "unit": "GB/s", "cores": cores,
+                               "kind": "port",
+                               "sample": f"rows [{s0},{s1}) of the same matrix ({n} rows, {k1 - k0} nnz, full x), "
+                                         f"{reps} passes, {t_cpu:.1f} s, oracle_spmv_csr_mt"}
+        # parity on the sample while both results are at hand (the oracle as checker)
+        y64, mag = orc.spmv_f64(rps, ci, va, x)
+        got = d_y[s0:s1].cpu().numpy().astype(np.float64)
+        out["parity_sample"] = {"rows": n, "max_err_over_1e-5_bound": float(np.max(np.abs(got - y64) / (1e-5 * mag + 1e-37))),
+                                "bit_identical_rows_vs_seq_oracle": int(np.sum(d_y[s0:s1].cpu().numpy() == y_cpu))}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""GPU (-m gpu): BASELINE.json's full sizes, checked through size-independent properties and a
+host-regenerated row sample (the oracle cannot walk 256Mi nonzeros in test time)."""
+import numpy as np
+import pytest
+
+from _util import RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[0, 1 << 16], ids=["uniform", "banded"])
+def c4(request, pkg, gpu):
+    import torch
+    W, capi = pkg.workloads, pkg.capi
+    w = W.config("c4", band=request.param)
+    rp = W.row_ptr(w)
+    assert int(rp[-1]) == 268_435_456 and w.rows == 16_777_216
+    d_rp = torch.from_numpy(rp).to(gpu)
+    d_ci = torch.empty(w.nnz, dtype=torch.int32, device=gpu)
+    d_va = torch.empty(w.nnz, dtype=torch.float32, device=gpu)
+    d_x = torch.empty(w.cols, dtype=torch.float32, device=gpu)
+    capi.synth_fill(w.seed, 0, w.rows, w.rows, w.cols, w.band, d_rp, d_ci, d_va)
+    capi.synth_x(w.seed, 0, w.cols, d_x)
+    A = capi.CsrMatrix.from_device(w.rows, w.cols, d_rp, d_ci, d_va)
+    Aabs = capi.CsrMatrix.from_device(w.rows, w.cols, d_rp, d_ci, d_va.abs())
+    for v in capi.VARIANTS.values():
+        A.plan(v)
+    Aabs.plan(capi.ADAPTIVE)
+    mag = torch.empty(w.rows, dtype=torch.float32, device=gpu)
+    Aabs.run(capi.ADAPTIVE, d_x.abs(), mag)          # sum_k |val_k x_k| per row: the error scale
+    torch.cuda.synchronize()
+    yield dict(w=w, rp=rp, d_rp=d_rp, d_ci=d_ci, d_va=d_va, d_x=d_x, A=A, mag=mag)
+    A.close(); Aabs.close()
+
+
+def _run(c4, pkg, variant, x=None):
+    import torch
+    y = torch.full((c4["w"].rows,), float("nan"), device=c4["d_x"].device)
+    c4["A"].run(variant, c4["d_x"] if x is None else x, y)
+    torch.cuda.synchronize()
+    return y
+
+
+def test_row_sample_matches_oracle(c4, pkg, oracle):
+    """1Mi rows (three separated windows incl. the first and last rows) regenerated on the host."""
+    w, rp = c4["w"], c4["rp"]
+    x = oracle.synth_x(w.seed, 0, w.cols)
+    assert np.array_equal(c4["d_x"].cpu().numpy().view(np.uint32), x.view(np.uint32))
+    ys = {n: _run(c4, pkg, v) for n, v in pkg.capi.VARIANTS.items()}
+    n = 1 << 18
+    for r0 in (0, 7_654_321, w.rows - n, 12_000_000):
+        r1 = r0 + n
+        rps = (rp[r0:r1 + 1].astype(np.int64) - int(rp[r0])).astype(np.int32)
+        ci, va = oracle.synth_fill(w.seed, r0, r1, w.rows, w.cols, w.band, rps)
+        k0, k1 = int(rp[r0]), int(rp[r1])
+        assert np.array_equal(c4["d_ci"][k0:k1].cpu().numpy(), ci)                 # indices bit-exact
+        assert np.array_equal(c4["d_va"][k0:k1].cpu().numpy().view(np.uint32), va.view(np.uint32))
+        y_seq = oracle.spmv(rps, ci, va, x)
+        y64, mag = oracle.spmv_f64(rps, ci, va, x)
+        for name, y in ys.items():
+            got = y[r0:r1].cpu().numpy()
+            if name == "scalar":
+                assert np.array_equal(got.view(np.uint32), y_seq.view(np.uint32))
+            err = np.abs(got.astype(np.float64) - y64)
+            assert np.all(err <= RTOL * mag + 1e-37), (name, r0, err.max())
+
+
+def test_all_variants_agree_on_every_row(c4, pkg):
+    """Every variant vs SCALAR (bit-identical to the oracle wherever sampled) on all 16Mi rows."""
+    import torch
+    ref = _run(c4, pkg, pkg.capi.SCALAR)
+    assert not torch.isnan(ref).any()
+    for name, v in pkg.capi.VARIANTS.items():
+        y = _run(c4, pkg, v)
+        assert not torch.isnan(y).any(), f"{name} left rows unwritten"
+        bad = ((y - ref).abs() > RTOL * c4["mag"] + 1e-37).sum().item()
+        assert bad == 0, f"{name}: {bad} rows differ from scalar beyond {RTOL}*sum|terms|"
+
+
+def test_linearity(c4, pkg):
+    """A(a*x1 + x2) == a*A(x1) + A(x2) within the fp32 bound -- no oracle needed at this size."""
+    import torch
+    dev = c4["d_x"].device
+    g = torch.Generator(device=dev).manual_seed(7)
+    x1 = c4["d_x"]
+    x2 = torch.rand(c4["w"].cols, device=dev, generator=g) * 2 - 1
+    a = 0.375
+    v = pkg.capi.ADAPTIVE
+    y1, y2, y12 = _run(c4, pkg, v, x1), _run(c4, pkg, v, x2), _run(c4, pkg, v, a * x1 + x2)
+    mag = c4["mag"] * (1 + abs(a)) + 1.0    # |A||x2| is bounded by sum|val| <= mag-ish scale; generous but linear
+    bad = ((y12 - (a * y1 + y2)).abs() > 4 * RTOL * mag).sum().item()
+    assert bad == 0
+
+
+def test_ones_vector_gives_row_sums(c4, pkg):
+    """x = 1 turns SpMV into per-row sums of vals: compare with a segmented sum done by torch."""
+    import torch
+    dev = c4["d_x"].device
+    ones = torch.ones(c4["w"].cols, device=dev)
+    y = _run(c4, pkg, pkg.capi.ADAPTIVE, ones)
+    csum = torch.cumsum(c4["d_va"].double(), 0)
+    rp = c4["d_rp"].long()
+    csum0 = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), csum])
+    rowsum = csum0[rp[1:]] - csum0[rp[:-1]]
+    lens = (rp[1:] - rp[:-1]).double()
+    assert ((y.double() - rowsum).abs() <= 1e-5 * lens + 1e-6).all()
