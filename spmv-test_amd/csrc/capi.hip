@@ -197,7 +197,7 @@ int spmv_csr_destroy(spmv_csr_t *h)
         if (p && hipFree(const_cast<void *>(p)) != hipSuccess) rc = SPMV_ERR_HIP;
     };
     if (h->owns_arrays) { fr(h->d_row_ptr); fr(h->d_col_idx); fr(h->d_vals); }
-    fr(h->d_chunk_lb); fr(h->d_carry); fr(h->d_chunk_win);
+    destroy_plans(*h);
     delete h;
     if (rc) set_error("hipFree failed in spmv_csr_destroy");
     return rc;
@@ -248,8 +248,10 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
 {
     if (!h) return 0;
     switch (variant) {
-        case SPMV_ADAPTIVE: return (int64_t)(h->nchunks + 1) * 4 + (int64_t)h->nchunks * 8;  // lb + carry w/r
-        case SPMV_TILED: return (int64_t)(h->nchunks + 1) * 4 + (int64_t)h->nchunks * 16;
+        case SPMV_ADAPTIVE:  // chunk_lb read + carry written and re-read
+            return (int64_t)(h->plan_adaptive.nchunks + 1) * 4 + (int64_t)h->plan_adaptive.nchunks * 8;
+        case SPMV_TILED:     // + the two window words per chunk
+            return (int64_t)(h->plan_tiled.nchunks + 1) * 4 + (int64_t)h->plan_tiled.nchunks * 16;
         default: return 0;
     }
 }

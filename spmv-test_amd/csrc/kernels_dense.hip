@@ -153,10 +153,14 @@ int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out
 __global__ __launch_bounds__(kBlock) void k_gemv_naive(int M, int N, const float *__restrict__ A,
                                                        const float *__restrict__ x, float *__restrict__ y)
 {
+#pragma clang fp contract(off)
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= N) return;
     float acc = 0.0f;
-    for (int j = 0; j < M; ++j) acc = __fadd_rn(acc, __fmul_rn(x[j], A[(size_t)j * N + i]));
+    for (int j = 0; j < M; ++j) {
+        float p = x[j] * A[(size_t)j * N + i];
+        acc = acc + p;
+    }
     y[i] = acc;
 }
 
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_gemv_naive(int M, int N, const float
 __global__ __launch_bounds__(kBlock) void k_gemv_xtile(int M, int N, const float *__restrict__ A,
                                                        const float *__restrict__ x, float *__restrict__ y)
 {
+#pragma clang fp contract(off)
     __shared__ float xs[1024];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     float acc = 0.0f;
@@ -173,7 +178,10 @@ __global__ __launch_bounds__(kBlock) void k_gemv_xtile(int M, int N, const float
         __syncthreads();
         const int jn = (M - jb) < 1024 ? (M - jb) : 1024;
         if (i < N)
-            for (int j = 0; j < jn; ++j) acc = __fadd_rn(acc, __fmul_rn(xs[j], A[(size_t)(jb + j) * N + i]));
+            for (int j = 0; j < jn; ++j) {
+                float p = xs[j] * A[(size_t)(jb + j) * N + i];
+                acc = acc + p;
+            }
     }
     if (i < N) y[i] = acc;
 }

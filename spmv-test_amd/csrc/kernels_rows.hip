@@ -21,13 +21,16 @@ __global__ __launch_bounds__(kBlock) void k_scalar(int64_t rows, const int32_t *
                                                    const float *__restrict__ vals,
                                                    const float *__restrict__ x, float *__restrict__ y)
 {
+    // two roundings per term, like the host loop: HIP's __fmul_rn/__fadd_rn are plain operators
+    // that hipcc would contract into v_fma_f32 under its default -ffp-contract=fast
+#pragma clang fp contract(off)
     int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= rows) return;
     int32_t b = row_ptr[r], e = row_ptr[r + 1];
     float acc = 0.0f;
     for (int32_t k = b; k < e; ++k) {
-        // two roundings, like the host loop (no fma contraction)
-        acc = __fadd_rn(acc, __fmul_rn(x[col_idx[k]], vals[k]));
+        float p = x[col_idx[k]] * vals[k];
+        acc = acc + p;
     }
     y[r] = acc;
 }

@@ -22,12 +22,20 @@ constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kBlock = 256;        // 4 waves: one per SIMD of a CU
 constexpr int kXcds = 8;           // MI355X: 8 XCDs, blocks dealt round-robin over them
 
-// ADAPTIVE / TILED chunking: every workgroup streams kChunk consecutive
-// nonzeros (col_idx + vals = 8 B each) with 16-byte loads per lane.
+// ADAPTIVE / TILED chunking: every lane streams kNnzPerThread consecutive-by-4 nonzeros
+// (col_idx + vals = 8 B each) with 16-byte loads; a workgroup of B threads owns B*16 nonzeros.
 constexpr int kNnzPerThread = 16;
-constexpr int kChunk = kBlock * kNnzPerThread;     // 4096 nnz = 32 KiB of stream per workgroup
-constexpr int kShortSeg = 32;                      // row segments up to this long: one lane sums them
-constexpr int kTileMaxCols = 8192;                 // TILED: widest x window staged in LDS (32 KiB)
+constexpr int kShortSeg = 16;                      // row segments up to this long: one lane sums them
+
+// Chunk boundaries (and, for TILED, column windows) for workgroups of `block` threads.
+struct ChunkPlan {
+    int block = 0;             // 0 = not planned; 256 | 512 | 1024 threads per workgroup
+    int nchunks = 0;           // ceil(nnz / (block*16))
+    int32_t *d_lb = nullptr;   // [nchunks+1] first row whose row_ptr >= c*chunk
+    float *d_carry = nullptr;  // [nchunks]   partial sum of the row continued from chunk c-1
+    int32_t *d_win = nullptr;  // [2*nchunks+2] TILED: first column, window length (0 = not staged); stats
+    int window_max = 0;        // widest window any chunk stages in LDS (floats)
+};
 
 }  // namespace spmv
 
@@ -41,13 +49,9 @@ struct spmv_csr {
     int device = 0;
 
     // plan state
-    int vector_width = 0;          // SPMV_VECTOR: lanes per row (2..64), 0 = not planned
-    int nchunks = 0;               // ADAPTIVE/TILED: ceil(nnz / kChunk)
-    int32_t *d_chunk_lb = nullptr; // [nchunks+1] first row whose row_ptr >= c*kChunk
-    float *d_carry = nullptr;      // [nchunks]   partial sum of the row continued from chunk c-1
-    int32_t *d_chunk_win = nullptr;// [2*nchunks] TILED: min column, window length (0 = too wide)
-    bool planned_adaptive = false;
-    bool planned_tiled = false;
+    int vector_width = 0;          // SPMV_VECTOR: lanes per row (2..32), 0 = not planned
+    spmv::ChunkPlan plan_adaptive; // SPMV_ADAPTIVE: 256-thread workgroups
+    spmv::ChunkPlan plan_tiled;    // SPMV_TILED: workgroup size chosen from the column windows
 };
 
 namespace spmv {
@@ -60,6 +64,7 @@ int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hip
 
 int plan_vector(spmv_csr &h, hipStream_t s);
 int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s);
+void destroy_plans(spmv_csr &h);
 
 int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out);
 int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s);
