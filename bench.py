@@ -6,7 +6,10 @@ A "step" is one pass of the hot path over the synthetic matrix: y = A x through 
 concatenates the output slices on every rank with one RCCL all-gather (BASELINE north_star).
 
   N = 1   config 4 of BASELINE.json: 16Mi x 16Mi, 256Mi nnz, mixed row lengths (the config the
-          metric/target is quoted on); inputs resident in HBM before the timed region.
+          metric/target is quoted on); inputs resident in HBM before the timed region.  BASELINE
+          fixes the row-length law, not the column law; the headline uses banded columns
+          (band 8192 = the 2-D 4096 x 4096 mesh coupling of a 16Mi-unknown problem) and the same
+          line reports the other column laws, uniform-random included, under "other_workloads".
   N > 1   config 5 generalised: (N*16Mi)^2, one 16Mi-row / 256Mi-nnz block per rank (weak
           scaling: per-GPU work fixed), x (N*64 MiB) on every rank, y all-gathered every step.
 
@@ -38,12 +41,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--variant", default=os.environ.get("SPMV_BENCH_VARIANT", "adaptive"))
+    ap.add_argument("--variant", default=os.environ.get("SPMV_BENCH_VARIANT", "tiled"))
     ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"], help="N=1 workload (default: c4)")
-    ap.add_argument("--band", type=int, default=int(os.environ.get("SPMV_BENCH_BAND", "0")),
-                    help="0 = uniform columns (default), >0 = diagonal band of that many columns")
+    ap.add_argument("--band", type=int, default=int(os.environ.get("SPMV_BENCH_BAND", "8192")),
+                    help="column law: >0 = diagonal band of that many columns (default 8192), 0 = uniform random")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other column laws / configs (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 21)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 23)
+    ap.add_argument("--rows-per-gpu", type=int, default=16 << 20, help="N>1: rows of each rank's block (default 16Mi)")
+    ap.add_argument("--backend", default=os.environ.get("SPMV_BENCH_BACKEND", "nccl"),
+                    help="nccl (= RCCL, default) | gloo (rehearsal of the N>1 path with ranks sharing one GPU)")
     return ap.parse_args()
 
 
@@ -65,11 +72,16 @@ def main():
     capi, W = pkg.capi, pkg.workloads
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: libspmv_hip has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     variant = capi.VARIANTS[args.variant]
 
@@ -78,7 +90,7 @@ def main():
         w = W.config(args.config, band=args.band)
         r0, r1 = 0, w.rows
     else:
-        w = W.c5(world, band=args.band)
+        w = W.c5(world, band=args.band, rows_per_gpu=args.rows_per_gpu)
         r0, r1 = rank * (w.rows // world), (rank + 1) * (w.rows // world)
     t_setup = time.perf_counter()
     rp = W.row_ptr(w, r0, r1 - r0)
@@ -163,7 +175,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": w.describe(), "variant": args.variant,
                        "rows_per_gpu": r1 - r0, "nnz_per_gpu": nnz_local,
-                       "parallelism": "single GPU" if world == 1 else f"row-block x{world}, all-gather(y) per step",
+                       "parallelism": "single GPU" if world == 1 else
+                       f"row-block x{world}, all-gather(y) per step over {args.backend}",
                        "algorithmic_bytes_per_gpu": bytes_rank},
             "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBS, 2),
             "gflops": round(gflops, 1),
@@ -186,10 +199,12 @@ def main():
         ci = d_ci[k0:k1].cpu().numpy()
         va = d_va[k0:k1].cpu().numpy()
         x = d_x.cpu().numpy()
-        cores = os.cpu_count() or 1
+        # the GPU box gives one GPU a 16-CPU share of a much larger host: use that many threads
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = int(os.environ.get("SPMV_CPU_THREADS", min(avail, 16)))
         y_cpu = orc.spmv(rps, ci, va, x, threads=cores)            # untimed first touch
         reps, t_cpu = 0, 0.0
-        while t_cpu < 8.0 and reps < 200:
+        while t_cpu < 10.0 and reps < 5000:
             t1 = time.perf_counter()
             y_cpu = orc.spmv(rps, ci, va, x, threads=cores)
             t_cpu += time.perf_counter() - t1
@@ -204,6 +219,41 @@ def main():
         got = d_y[s0:s1].cpu().numpy().astype(np.float64)
         out["parity_sample"] = {"rows": n, "max_err_over_1e-5_bound": float(np.max(np.abs(got - y64) / (1e-5 * mag + 1e-37))),
                                 "bit_identical_rows_vs_seq_oracle": int(np.sum(d_y[s0:s1].cpu().numpy() == y_cpu))}
+
+    # ---- the other column laws and configs, kernel time only (N = 1) ------------------------------
+    if rank == 0 and world == 1 and not args.no_extras:
+        del A, d_rp, d_ci, d_va, d_x, d_y
+        torch.cuda.empty_cache()
+        extras = []
+        todo = [("c4", 0), ("c4", 2048), ("c4", 65536), ("c2", 0), ("c2", 8192), ("c3", 0), ("c3", 8192)]
+        for cname, band in todo:
+            if cname == args.config and band == args.band:
+                continue
+            we = W.config(cname, band=band)
+            rpe = W.row_ptr(we)
+            e_rp = torch.from_numpy(rpe).to(dev)
+            e_ci = torch.empty(we.nnz, dtype=torch.int32, device=dev)
+            e_va = torch.empty(we.nnz, dtype=torch.float32, device=dev)
+            e_x = torch.empty(we.cols, dtype=torch.float32, device=dev)
+            e_y = torch.empty(we.rows, dtype=torch.float32, device=dev)
+            capi.synth_fill(we.seed, 0, we.rows, we.rows, we.cols, we.band, e_rp, e_ci, e_va)
+            capi.synth_x(we.seed, 0, we.cols, e_x)
+            Ae = capi.CsrMatrix.from_device(we.rows, we.cols, e_rp, e_ci, e_va)
+            be = W.algorithmic_bytes(we.rows, we.cols, we.nnz)
+            best = None
+            for vn in ("adaptive", "tiled", "vector"):
+                v = capi.VARIANTS[vn]
+                Ae.plan(v)
+                Ae.time(v, e_x, e_y, 3)
+                ms = min(Ae.time(v, e_x, e_y, 20) for _ in range(2))
+                if best is None or ms < best[1]:
+                    best = (vn, ms)
+            extras.append({"workload": we.describe(), "variant": best[0], "kernel_ms": round(best[1], 5),
+                           "GBs": round(be / best[1] / 1e6, 1), "frac_of_peak": round(be / best[1] / 1e6 / HBM_PEAK_GBS, 4)})
+            Ae.close()
+            del e_rp, e_ci, e_va, e_x, e_y
+            torch.cuda.empty_cache()
+        out["other_workloads"] = extras
 
     if rank == 0:
         print(json.dumps(out), flush=True)

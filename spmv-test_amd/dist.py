@@ -44,7 +44,12 @@ class ShardedSpmv:
 
     def broadcast_x(self, src: int = 0) -> None:
         """The one-off distribution of the dense vector."""
-        dist.broadcast(self.x, src=src, group=self.group)
+        if self.x.device.type == "cuda" and dist.get_backend(self.group) != "nccl":
+            host = self.x.cpu()
+            dist.broadcast(host, src=src, group=self.group)
+            self.x.copy_(host)
+        else:
+            dist.broadcast(self.x, src=src, group=self.group)
 
     def multiply(self) -> None:
         """Local row block only (no communication)."""
@@ -53,9 +58,17 @@ class ShardedSpmv:
     def gather(self) -> torch.Tensor:
         """Concatenate the slices on every rank; returns the full y."""
         if self.world > 1:
-            # in-place all-gather: rank r's slot already holds its slice
-            dist.all_gather_into_tensor(self.y_slots, self.y_local.clone() if self.y_slots.device.type == "cpu"
-                                        else self.y_local, group=self.group)
+            backend = dist.get_backend(self.group)
+            if self.y_slots.device.type == "cuda" and backend != "nccl":
+                # rehearsal path (gloo ranks sharing one GPU): stage through the host
+                slots = torch.empty(self.y_slots.shape, dtype=torch.float32)
+                dist.all_gather_into_tensor(slots, self.y_local.cpu(), group=self.group)
+                self.y_slots.copy_(slots)
+            else:
+                # in-place all-gather: rank r's slot already holds its slice (RCCL accepts
+                # sendbuff == recvbuff + rank*count); gloo on CPU wants a separate input
+                src = self.y_local.clone() if self.y_slots.device.type == "cpu" else self.y_local
+                dist.all_gather_into_tensor(self.y_slots, src, group=self.group)
         if not self.uniform:
             for p in range(self.world):
                 n = self.bounds[p + 1] - self.bounds[p]

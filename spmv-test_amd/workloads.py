@@ -192,7 +192,7 @@ CONFIGS = {
     "c4": Workload("c4", 16 * Mi, 16 * Mi, "mixed", 16),
     # c5 is c4's row-length law on (N_gpus * 16Mi)^2, one 16Mi-row block per GPU
 }
-C4_BAND = 1 << 16
+C4_BAND = 8192     # headline column law: half-bandwidth 4096 = the 2-D 4096 x 4096 mesh of 16Mi unknowns
 
 
 def config(name: str, band: int | None = None, scale: float = 1.0) -> Workload:
@@ -206,7 +206,9 @@ def config(name: str, band: int | None = None, scale: float = 1.0) -> Workload:
     return w
 
 
-def c5(n_gpus: int, band: int = 0) -> Workload:
+def c5(n_gpus: int, band: int = 0, rows_per_gpu: int = 16 * Mi) -> Workload:
     """Config 5 generalised: (n_gpus*16Mi)^2, 256Mi nonzeros per 16Mi-row block (weak scaling)."""
-    r = n_gpus * 16 * Mi
+    if rows_per_gpu % BLOCK_ROWS:
+        raise ValueError("rows_per_gpu must be a multiple of 65 536")
+    r = n_gpus * rows_per_gpu
     return Workload(f"c5x{n_gpus}", r, r, "mixed", 16, band=band)

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""tools/summarize_profile.py <tag> -- condense gpurun_out/prof_<tag>/ (tools/profile.sh) into profiles/.
+
+Writes  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+        profiles/<tag>_pmc_summary.json   per-kernel means of FETCH_SIZE / WRITE_SIZE (separate passes) and
+                                          the calibration on a pure 16-B/lane stream of known size
+        profiles/traffic.json             HBM bytes per launch of the dominant kernel, read by bench.py
+Correction (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the
+128-B requests of a wide coalesced read at 64 B, i.e. reports exactly half the bytes -> read bytes =
+2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.  The calibration section re-measures that factor here."""
+import csv
+import glob
+import json
+import shutil
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def means(path):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def main():
+    tag = sys.argv[1]
+    src = ROOT / "gpurun_out" / f"prof_{tag}"
+    dst = ROOT / "profiles"
+    dst.mkdir(exist_ok=True)
+    stats = glob.glob(str(src / "trace" / "*" / "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, dst / f"{tag}_kernel_stats.csv")
+    fetch = means(glob.glob(str(src / "fetch" / "*" / "*_counter_collection.csv"))[0])
+    write = means(glob.glob(str(src / "write" / "*" / "*_counter_collection.csv"))[0])
+    cal_f = means(glob.glob(str(src / "cal_fetch" / "*" / "*_counter_collection.csv"))[0])
+    cal_w = means(glob.glob(str(src / "cal_write" / "*" / "*_counter_collection.csv"))[0])
+    bench = json.loads((src / "bench_trace.json").read_text().strip().splitlines()[-1])
+
+    # calibration: k_stream<16,false> reads exactly 2^31 B (2^28 col_idx + 2^28 vals) and writes 2^26 B
+    ck = next(k for k in cal_f if "k_stream<16, false>" in k)
+    known_read, known_write = float(1 << 31), float(1 << 26)
+    read_factor = known_read / (cal_f[ck][0] * 1024)
+    write_factor = known_write / (cal_w[ck][0] * 1024)
+
+    kernels = {}
+    for k in fetch:
+        if not k.startswith(("void spmv::", "spmv::")):
+            continue
+        f_kib, n = fetch[k]
+        w_kib = write.get(k, (0.0, 0))[0]
+        kernels[k] = {"launches": n, "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
+                      "hbm_bytes_per_launch": int(round((2 * f_kib + w_kib) * 1024))}
+    dom = next(k for k in kernels if "k_adaptive" in k)
+    summary = {"tag": tag, "command": "python3 bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline",
+               "workload": bench["config"]["workload"], "variant": bench["config"]["variant"],
+               "calibration": {"kernel": ck, "known_read_bytes": int(known_read), "FETCH_SIZE_KiB": cal_f[ck][0],
+                               "read_bytes_per_FETCH_KiB": round(read_factor * 1024, 2),
+                               "read_correction_factor": round(read_factor, 4),
+                               "known_write_bytes": int(known_write), "WRITE_SIZE_KiB": cal_w[ck][0],
+                               "write_correction_factor": round(write_factor, 4)},
+               "kernels": kernels, "dominant_kernel": dom,
+               "algorithmic_bytes_per_launch": bench["config"]["algorithmic_bytes_per_gpu"],
+               "traffic_over_algorithmic": round(kernels[dom]["hbm_bytes_per_launch"] /
+                                                 bench["config"]["algorithmic_bytes_per_gpu"], 4),
+               "bench_line_under_profiler": bench}
+    (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(summary, indent=1))
+    tfile = dst / "traffic.json"
+    tj = json.loads(tfile.read_text()) if tfile.exists() else {}
+    wname = bench["config"]["workload"].split(":")[0]
+    band = 0
+    if "band " in bench["config"]["workload"]:
+        band = int(bench["config"]["workload"].split("band ")[1].split(")")[0])
+    tj[f"{bench['config']['variant']}:{wname}:band{band}"] = {
+        "hbm_bytes_per_launch": kernels[dom]["hbm_bytes_per_launch"], "kernel": dom, "profile": f"{tag}_pmc_summary.json"}
+    tfile.write_text(json.dumps(tj, indent=1))
+    print(json.dumps({k: summary[k] for k in ("calibration", "dominant_kernel", "traffic_over_algorithmic")}, indent=1))
+    print(open(dst / f"{tag}_kernel_stats.csv").read())
+
+
+if __name__ == "__main__":
+    main()

@@ -106,6 +106,52 @@ __global__ __launch_bounds__(BS) void k_lds_reduce(const int* __restrict__ col, 
     }
 }
 
+// stage 3: x window staged in LDS (aliased with the product buffer), gathers from LDS.
+// MODE 0 = full, 1 = window loads skipped (barriers kept), 2 = window via LDS-DMA (global_load_lds)
+template <int BLK, int MODE>
+__global__ __launch_bounds__(BLK, 8) void k_win(const int* __restrict__ col, const float* __restrict__ val, const float* __restrict__ x,
+                                                float* __restrict__ y, int per_row, int band, int64_t cols) {
+    constexpr int NPT = 16, V = 4, T = BLK * NPT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * T;
+    const i4* c4 = reinterpret_cast<const i4*>(col + base);
+    const f4* v4 = reinterpret_cast<const f4*>(val + base);
+    i4 cc[V]; f4 vv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { cc[j] = __builtin_nontemporal_load(&c4[j * BLK + tid]); vv[j] = __builtin_nontemporal_load(&v4[j * BLK + tid]); }
+    // window of this chunk: rows [r0, r0 + T/per_row), columns [r0 - band/2, r0 + rows + band/2)
+    const int64_t r0 = base / per_row; const int nrows = T / per_row;
+    int64_t w0 = r0 - band / 2; if (w0 < 0) w0 = 0; w0 &= ~3ll;
+    int64_t w1 = r0 + nrows + band / 2 + 4; if (w1 > cols) w1 = cols;
+    const int wlen = (int)(w1 - w0);
+    if (MODE == 0) {
+        for (int i = tid * 4; i < wlen; i += BLK * 4) *reinterpret_cast<f4*>(smem + i) = *reinterpret_cast<const f4*>(x + w0 + i);
+    } else if (MODE == 2) {
+        for (int i = tid * 4; i < wlen; i += BLK * 4)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(x + w0 + i),
+                                             (void __attribute__((address_space(3)))*)(smem + (i - tid * 4)), 16, 0, 0);
+    }
+    __syncthreads();
+    f4 xv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int o = cc[j][q] - (int)w0; o = o < 0 ? 0 : (o >= wlen ? wlen - 1 : o); xv[j][q] = smem[o]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int p0 = pad_idx((j * BLK + tid) * 4);
+        smem[p0] = vv[j][0] * xv[j][0]; smem[p0 + 1] = vv[j][1] * xv[j][1]; smem[p0 + 2] = vv[j][2] * xv[j][2]; smem[p0 + 3] = vv[j][3] * xv[j][3];
+    }
+    __syncthreads();
+    for (int r = tid; r < nrows; r += BLK) {
+        float acc = 0.f;
+        for (int i = r * per_row; i < (r + 1) * per_row; ++i) acc += smem[pad_idx(i)];
+        y[r0 + r] = acc;
+    }
+}
+
 template <typename F>
 float timeit(F f, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -146,5 +192,12 @@ int main(int argc, char** argv) {
     RUN("lds_reduce", 16, (k_lds_reduce<16, false><<<nnz / (BS * 16), BS>>>(col, val, x, y, per_row)), bytes_alg)
     RUN("lds_reduce nt", 8, (k_lds_reduce<8, true><<<nnz / (BS * 8), BS>>>(col, val, x, y, per_row)), bytes_alg)
     RUN("lds_reduce nt", 16, (k_lds_reduce<16, true><<<nnz / (BS * 16), BS>>>(col, val, x, y, per_row)), bytes_alg)
+    if (band <= 16384) {
+#define RUNW(BLK, MODE, name) { size_t lds = (size_t)BLK * 18 * 4; CK(hipFuncSetAttribute((const void*)&k_win<BLK, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if ((size_t)(band + BLK + 8) * 4 <= lds) RUN(name, BLK, (k_win<BLK, MODE><<<nnz / (BLK * 16), BLK, lds>>>(col, val, x, y, per_row, (int)band, cols)), bytes_alg) }
+        RUNW(256, 0, "win full blk") RUNW(256, 1, "win noload blk") RUNW(256, 2, "win ldsdma blk")
+        RUNW(512, 0, "win full blk") RUNW(512, 1, "win noload blk") RUNW(512, 2, "win ldsdma blk")
+        RUNW(1024, 0, "win full blk") RUNW(1024, 1, "win noload blk") RUNW(1024, 2, "win ldsdma blk")
+    }
     return 0;
 }
