@@ -59,6 +59,14 @@ class SpmvError(RuntimeError):
 _lib = None
 
 
+def use_library(path) -> None:
+    """Development aid (tools/explore.py A/B runs): bind to another build of libspmv_hip.so.
+    Handles created before the switch must already be closed."""
+    global _lib, LIB_PATH
+    LIB_PATH = Path(path).resolve()
+    _lib = None
+
+
 def lib() -> C.CDLL:
     """Load libspmv_hip.so (once).  Fails loudly when it has not been built."""
     global _lib
@@ -70,7 +78,7 @@ def lib() -> C.CDLL:
         # torch bundles its own libamdhip64.so.7; importing it first makes this library bind to
         # the same HIP runtime instance, so torch device pointers and streams are valid here.
         import torch  # noqa: F401
-        l = C.CDLL(os.fspath(LIB_PATH), mode=C.RTLD_GLOBAL)
+        l = C.CDLL(os.fspath(LIB_PATH), mode=C.RTLD_LOCAL)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args

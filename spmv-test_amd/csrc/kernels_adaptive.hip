@@ -46,6 +46,8 @@ __host__ __device__ constexpr int prod_words(int block) { return chunk_of(block)
 __host__ __device__ constexpr int region_words(int block) { return block * 18; }
 static_assert(region_words(256) >= prod_words(256), "region must hold the products");
 __host__ __device__ constexpr int max_long(int block) { return chunk_of(block) / (kShortSeg + 1) + 2; }
+constexpr int kHugeSeg = 512;  // segments longer than this are summed by the whole workgroup
+__host__ __device__ constexpr int max_huge(int block) { return chunk_of(block) / (kHugeSeg + 1) + 2; }
 
 __device__ __forceinline__ int pad_idx(int i) { return i + (i >> 5); }
 
@@ -74,45 +76,85 @@ __global__ void k_plan_chunks(int64_t rows, int nchunks, int chunk, const int32_
     lb[c] = (int32_t)lo;
 }
 
-// plan (TILED): column window of every chunk -> win[2c] = first column (aligned down to 4),
-// win[2c+1] = window length in floats, 0 when wider than `cap`; stats[0] = widest staged window,
-// stats[1] = number of chunks whose window fits.
-__global__ __launch_bounds__(256) void k_plan_windows(int64_t nnz, int nchunks, int chunk,
+// plan (TILED): what part of x chunk c stages in LDS.
+//   win[2c]   = first staged column w0 (multiple of 4)
+//   win[2c+1] = staged length wlen in floats (0 = nothing staged) | kOutsideBit when some of the
+//               chunk's columns lie outside [w0, w0+wlen) and are gathered from global memory
+// A chunk whose whole column span [min, max] fits `maxpass` LDS regions is staged completely (in
+// ceil(span/region) passes).  A wider one stages ONE region centred on the mean column (the dense
+// part of a banded chunk that also holds a few very long rows) if that covers >= 1/4 of its
+// nonzeros.  stats[0] = chunks staged in a single pass with nothing outside, stats[1] = chunks
+// staged completely (any number of passes).
+constexpr int kOutsideBit = 1 << 30;
+
+__global__ __launch_bounds__(256) void k_plan_windows(int64_t nnz, int64_t cols, int nchunks, int chunk,
                                                       const int32_t *__restrict__ col_idx,
-                                                      int32_t *__restrict__ win, int32_t *__restrict__ stats, int cap)
+                                                      int32_t *__restrict__ win, int32_t *__restrict__ stats,
+                                                      int region, int maxpass)
 {
-    __shared__ int s_min[4], s_max[4];
+    __shared__ int s_min[4], s_max[4], s_cnt[4];
+    __shared__ long long s_sum[4];
+    __shared__ int s_w0;
     const int c = blockIdx.x;
+    const int wv = threadIdx.x >> 6;
+    const bool lane0 = (threadIdx.x & (kWave - 1)) == 0;
     const int64_t base = (int64_t)c * chunk;
     const int n = (int)((nnz - base) < chunk ? (nnz - base) : chunk);
     int mn = 0x7fffffff, mx = -1;
+    long long sum = 0;
     for (int i = threadIdx.x; i < n; i += 256) {
         int v = col_idx[base + i];
         mn = v < mn ? v : mn;
         mx = v > mx ? v : mx;
+        sum += v;
     }
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) {
         int a = __shfl_down(mn, o, kWave), b = __shfl_down(mx, o, kWave);
         mn = a < mn ? a : mn;
         mx = b > mx ? b : mx;
+        sum += __shfl_down(sum, o, kWave);
     }
-    if ((threadIdx.x & (kWave - 1)) == 0) { s_min[threadIdx.x >> 6] = mn; s_max[threadIdx.x >> 6] = mx; }
+    if (lane0) { s_min[wv] = mn; s_max[wv] = mx; s_sum[wv] = sum; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) {
-            mn = s_min[w] < mn ? s_min[w] : mn;
-            mx = s_max[w] > mx ? s_max[w] : mx;
-        }
-        const int w0 = mn & ~3;
-        const int64_t len = (int64_t)mx + 1 - w0;
-        const int32_t wl = (mx >= 0 && len <= cap) ? (int32_t)len : 0;
-        win[2 * c] = w0;
-        win[2 * c + 1] = wl;
-        if (wl > 0) {
-            atomicMax(&stats[0], wl);
+    for (int w = 0; w < 4; ++w) {  // every thread folds the four partials
+        mn = w == 0 ? s_min[0] : (s_min[w] < mn ? s_min[w] : mn);
+        mx = w == 0 ? s_max[0] : (s_max[w] > mx ? s_max[w] : mx);
+    }
+    const int w0_full = mn & ~3;
+    const int64_t span = (int64_t)mx + 1 - w0_full;
+    if (span <= (int64_t)region * maxpass) {
+        if (threadIdx.x == 0) {
+            win[2 * c] = w0_full;
+            win[2 * c + 1] = (int32_t)span;
+            if (span <= region) atomicAdd(&stats[0], 1);
             atomicAdd(&stats[1], 1);
         }
+        return;
+    }
+    // too wide: one region around the mean column, if it is worth it
+    if (threadIdx.x == 0) {
+        const long long tot = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        long long w0 = tot / (n > 0 ? n : 1) - region / 2;
+        if (w0 > cols - region) w0 = cols - region;
+        if (w0 < 0) w0 = 0;
+        s_w0 = (int)(w0 & ~3ll);
+    }
+    __syncthreads();
+    const int w0 = s_w0;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += 256) cnt += ((unsigned)(col_idx[base + i] - w0) < (unsigned)region) ? 1 : 0;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, kWave);
+    if (lane0) s_cnt[wv] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const bool stage = 4 * (int64_t)cnt >= n;
+        int64_t wl = region;
+        if (w0 + wl > cols) wl = cols - w0;
+        win[2 * c] = w0;
+        win[2 * c + 1] = stage ? ((int32_t)wl | kOutsideBit) : 0;
     }
 }
 
@@ -124,17 +166,17 @@ struct Segment {
     float *dst;
 };
 
-__device__ __forceinline__ Segment make_segment(int t, int lb0, int64_t base, int64_t lim, int64_t rb, int64_t re,
+__device__ __forceinline__ Segment make_segment(int t, int lb0, int64_t base, int64_t lim, int32_t rb, int32_t re,
                                                 float *__restrict__ y, float *__restrict__ carry, int c)
 {
     Segment g;
     if (t == 0) {  // rb = row_ptr[lb0]
         g.s = 0;
-        g.e = (int)((rb < lim ? rb : lim) - base);
+        g.e = (int)(((int64_t)rb < lim ? (int64_t)rb : lim) - base);
         g.dst = carry + c;
     } else {       // rb = row_ptr[r], re = row_ptr[r+1], r = lb0 + t - 1
-        g.s = (int)(rb - base);
-        g.e = (int)((re < lim ? re : lim) - base);
+        g.s = (int)((int64_t)rb - base);
+        g.e = (int)(((int64_t)re < lim ? (int64_t)re : lim) - base);
         g.dst = y + ((int64_t)lb0 + t - 1);
     }
     return g;
@@ -157,22 +199,27 @@ __global__ __launch_bounds__(BLOCK, 8) void k_adaptive(int64_t rows, int64_t nnz
     // gathers have landed in registers -- as the product staging buffer.
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int2 long_seg[max_long(BLOCK)];  // {segment id, first product | end product << 16}
-    __shared__ int long_count;
+    __shared__ int2 huge_seg[max_huge(BLOCK)];
+    __shared__ float wave_part[BLOCK / kWave];
+    __shared__ int long_count, huge_count;
 
     const int tid = threadIdx.x;
     const int c = xcd_chunk(blockIdx.x, nchunks);
     const int64_t base = (int64_t)c * kChunkT;
     const int n = (int)((nnz - base) < kChunkT ? (nnz - base) : kChunkT);
     const int64_t lim = base + n;
-    if (tid == 0) long_count = 0;
+    if (tid == 0) { long_count = 0; huge_count = 0; }
 
     // chunk metadata first: the row_ptr prefetch below depends on it
     const int lb0 = chunk_lb[c], lb1 = chunk_lb[c + 1];
     const int m = lb1 - lb0;
     int w0 = 0, wlen = 0;
+    bool outside = false;
     if (TILED) {
         w0 = win[2 * c];
-        wlen = win[2 * c + 1];
+        const int wl = win[2 * c + 1];
+        wlen = wl & (kOutsideBit - 1);
+        outside = (wl & kOutsideBit) != 0;
     }
 
     // ---- 1. stream the chunk: 16 B per lane per load (1 KiB contiguous per wave instruction),
@@ -205,30 +252,52 @@ __global__ __launch_bounds__(BLOCK, 8) void k_adaptive(int64_t rows, int64_t nnz
     }
 
     // ---- 2. row pointers of this lane's first segment, in flight together with the stream
-    int64_t rb0 = 0, re0 = 0;
-    if (tid <= m) {
+    int32_t rb0 = 0, re0 = 0;
+    if (!TILED && tid <= m) {
         rb0 = row_ptr[tid == 0 ? lb0 : lb0 + tid - 1];  // lb0 <= rows and row_ptr[rows] = nnz
         re0 = tid == 0 ? 0 : row_ptr[lb0 + tid];
     }
 
-    // ---- 3. gather x: from the LDS window when the plan found one, else through L1/L2
+    // ---- 3. gather x: from LDS where the plan staged a window, else through L1/L2
+    constexpr int kRegion = region_words(BLOCK);
     f4 xv[kVec];
     if (TILED && wlen > 0) {
-        for (int i = tid * 4; i < wlen; i += BLOCK * 4) {
-            if ((int64_t)w0 + i + 3 < cols) {
-                *reinterpret_cast<f4 *>(smem + i) = *reinterpret_cast<const f4 *>(x + w0 + i);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if ((int64_t)w0 + i + q < cols) smem[i + q] = x[w0 + i + q];
-            }
-        }
-        __syncthreads();
+        // ceil(wlen / kRegion) passes (one for a chunk whose column span fits the region): stage a
+        // slice of x, gather the nonzeros whose column lies in it.  Columns the plan left outside
+        // the staged range come straight from global memory (issued first).
 #pragma unroll
         for (int j = 0; j < kVec; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xv[j][q] = smem[cc[j][q] - w0];
-        __syncthreads();  // every gather has its value before the window is overwritten
+            for (int q = 0; q < 4; ++q) xv[j][q] = 0.0f;
+        if (outside) {
+#pragma unroll
+            for (int j = 0; j < kVec; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((unsigned)(cc[j][q] - w0) >= (unsigned)wlen) xv[j][q] = x[cc[j][q]];
+        }
+        for (int off = 0; off < wlen; off += kRegion) {
+            const int len = (wlen - off) < kRegion ? (wlen - off) : kRegion;
+            const int64_t g0 = (int64_t)w0 + off;
+            for (int i = tid * 4; i < len; i += BLOCK * 4) {
+                if (g0 + i + 3 < cols) {
+                    *reinterpret_cast<f4 *>(smem + i) = *reinterpret_cast<const f4 *>(x + g0 + i);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (g0 + i + q < cols) smem[i + q] = x[g0 + i + q];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kVec; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned o = (unsigned)(cc[j][q] - w0 - off);
+                    if (o < (unsigned)len) xv[j][q] = smem[o];
+                }
+            __syncthreads();  // every gather has its value before the slice is overwritten
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < kVec; ++j)
@@ -250,9 +319,9 @@ __global__ __launch_bounds__(BLOCK, 8) void k_adaptive(int64_t rows, int64_t nnz
     // ---- 5. short segments: one lane each, sequential (the oracle's order); longer ones are
     //         queued in LDS with their bounds so that phase 6 touches no global metadata
     for (int t = tid; t <= m; t += BLOCK) {
-        int64_t rb, re;
-        if (t == tid) { rb = rb0; re = re0; }
-        else { rb = row_ptr[lb0 + t - 1]; re = row_ptr[lb0 + t]; }
+        int32_t rb, re;
+        if (!TILED && t == tid) { rb = rb0; re = re0; }
+        else { rb = row_ptr[t == 0 ? lb0 : lb0 + t - 1]; re = t == 0 ? 0 : row_ptr[lb0 + t]; }
         const Segment g = make_segment(t, lb0, base, lim, rb, re, y, carry, c);
         if (g.e - g.s <= kShortSeg) {
             float acc = 0.0f;
@@ -264,9 +333,12 @@ __global__ __launch_bounds__(BLOCK, 8) void k_adaptive(int64_t rows, int64_t nnz
             }
             for (; i < g.e; ++i) acc += smem[pad_idx(i)];
             *g.dst = acc;
-        } else {
+        } else if (g.e - g.s <= kHugeSeg) {
             const int slot = atomicAdd(&long_count, 1);
             long_seg[slot] = make_int2(t, g.s | (g.e << 16));  // s < 2^14, e <= 2^14
+        } else {
+            const int slot = atomicAdd(&huge_count, 1);
+            huge_seg[slot] = make_int2(t, g.s | (g.e << 16));
         }
     }
     __syncthreads();
@@ -286,6 +358,27 @@ __global__ __launch_bounds__(BLOCK, 8) void k_adaptive(int64_t rows, int64_t nnz
             if (q.x == 0) carry[c] = acc;
             else y[(int64_t)lb0 + q.x - 1] = acc;
         }
+    }
+
+    // ---- 7. huge segments (a power-law row can fill the whole chunk): the whole workgroup
+    //         strides one segment, wavefront trees, then the per-wave partials in wave order
+    const int nhuge = huge_count;
+    for (int i = 0; i < nhuge; ++i) {
+        const int2 q = huge_seg[i];
+        const int qe = (int)((unsigned)q.y >> 16);
+        float acc = 0.0f;
+        for (int k = (q.y & 0xffff) + tid; k < qe; k += BLOCK) acc += smem[pad_idx(k)];
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+        if ((tid & (kWave - 1)) == 0) wave_part[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.0f;
+            for (int w = 0; w < BLOCK / kWave; ++w) tot += wave_part[w];
+            if (q.x == 0) carry[c] = tot;
+            else y[(int64_t)lb0 + q.x - 1] = tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -322,14 +415,17 @@ static void free_plan(ChunkPlan &p)
     p = ChunkPlan();
 }
 
-// chunk boundaries (+ column windows when `cap` > 0) for workgroups of `block` threads
-static int build_plan(const spmv_csr &h, int block, int cap, hipStream_t s, ChunkPlan &p, int *fits)
+static int max_passes(int block) { return block == 1024 ? 12 : (block == 512 ? 4 : 2); }
+
+// chunk boundaries (+ column windows when `windows`) for workgroups of `block` threads
+static int build_plan(const spmv_csr &h, int block, bool windows, hipStream_t s, ChunkPlan &p, int *single, int *full)
 {
     free_plan(p);
     p.block = block;
     const int chunk = chunk_of(block);
     p.nchunks = (int)((h.nnz + chunk - 1) / chunk);
-    if (fits) *fits = 0;
+    if (single) *single = 0;
+    if (full) *full = 0;
     if (p.nchunks == 0) return SPMV_OK;
     SPMV_HIP_TRY(hipMalloc((void **)&p.d_lb, sizeof(int32_t) * ((size_t)p.nchunks + 1)));
     SPMV_HIP_TRY(hipMalloc((void **)&p.d_carry, sizeof(float) * (size_t)p.nchunks));
@@ -337,19 +433,21 @@ static int build_plan(const spmv_csr &h, int block, int cap, hipStream_t s, Chun
                        h.d_row_ptr, p.d_lb);
     int rc = check_launch("k_plan_chunks");
     if (rc) return rc;
-    if (cap > 0) {
+    if (windows) {
         // [2*nchunks] windows + 2 words of statistics
         SPMV_HIP_TRY(hipMalloc((void **)&p.d_win, sizeof(int32_t) * (2 * (size_t)p.nchunks + 2)));
         int32_t *d_stats = p.d_win + 2 * (size_t)p.nchunks;
         SPMV_HIP_TRY(hipMemsetAsync(d_stats, 0, 2 * sizeof(int32_t), s));
-        hipLaunchKernelGGL(k_plan_windows, dim3(p.nchunks), dim3(256), 0, s, h.nnz, p.nchunks, chunk, h.d_col_idx,
-                           p.d_win, d_stats, cap);
+        hipLaunchKernelGGL(k_plan_windows, dim3(p.nchunks), dim3(256), 0, s, h.nnz, h.cols, p.nchunks, chunk,
+                           h.d_col_idx, p.d_win, d_stats, region_words(block), max_passes(block));
         if ((rc = check_launch("k_plan_windows"))) return rc;
         int32_t stats[2] = {0, 0};
         SPMV_HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, s));
         SPMV_HIP_TRY(hipStreamSynchronize(s));
-        p.window_max = stats[0];
-        if (fits) *fits = stats[1];
+        p.staged_single = stats[0];
+        p.staged_full = stats[1];
+        if (single) *single = stats[0];
+        if (full) *full = stats[1];
     }
     return SPMV_OK;
 }
@@ -358,26 +456,29 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
 {
     if (!tiled) {
         if (h.plan_adaptive.block) return SPMV_OK;
-        return build_plan(h, 256, 0, s, h.plan_adaptive, nullptr);
+        return build_plan(h, 256, false, s, h.plan_adaptive, nullptr, nullptr);
     }
     if (h.plan_tiled.block) return SPMV_OK;
-    // smallest workgroup whose LDS region holds the x window of >= 90 % of the chunks; if even
-    // 1024 threads do not reach 50 %, the matrix has no usable column locality: stay at 256.
+    // Workgroup size: the smallest whose LDS region holds the whole column span of >= 90 % of the
+    // chunks in ONE pass (same LDS bytes and waves per CU for all three, but a larger workgroup
+    // pays more per barrier).  Failing that, 1024 threads with multi-pass staging when that
+    // covers at least half of the chunks; otherwise the matrix has no usable column locality and
+    // 256-thread workgroups gather from global memory (staging only what is worth it).
     int forced = 0;
     if (const char *e = getenv("SPMV_TILED_BLOCK")) forced = atoi(e);  // tuning knob: 256 | 512 | 1024
     if (forced != 256 && forced != 512 && forced != 1024) forced = 0;
+    if (forced) return build_plan(h, forced, true, s, h.plan_tiled, nullptr, nullptr);
     const int cands[3] = {256, 512, 1024};
+    int full1024 = 0;
     for (int k = 0; k < 3; ++k) {
-        const int block = cands[k];
-        if (forced && block != forced) continue;
-        int fits = 0;
-        int rc = build_plan(h, block, region_words(block), s, h.plan_tiled, &fits);
+        int single = 0, full = 0;
+        int rc = build_plan(h, cands[k], true, s, h.plan_tiled, &single, &full);
         if (rc) return rc;
-        if (forced || h.plan_tiled.nchunks == 0 || fits >= 0.9 * h.plan_tiled.nchunks) return SPMV_OK;
-        if (block == 1024 && fits >= 0.5 * h.plan_tiled.nchunks) return SPMV_OK;
+        if (h.plan_tiled.nchunks == 0 || single >= 0.9 * h.plan_tiled.nchunks) return SPMV_OK;
+        full1024 = full;
     }
-    int fits = 0;
-    return build_plan(h, 256, region_words(256), s, h.plan_tiled, &fits);
+    if (full1024 >= 0.5 * h.plan_tiled.nchunks) return SPMV_OK;  // keep the 1024-thread multi-pass plan
+    return build_plan(h, 256, true, s, h.plan_tiled, nullptr, nullptr);
 }
 
 void destroy_plans(spmv_csr &h)

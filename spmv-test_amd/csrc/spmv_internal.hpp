@@ -34,7 +34,8 @@ struct ChunkPlan {
     int32_t *d_lb = nullptr;   // [nchunks+1] first row whose row_ptr >= c*chunk
     float *d_carry = nullptr;  // [nchunks]   partial sum of the row continued from chunk c-1
     int32_t *d_win = nullptr;  // [2*nchunks+2] TILED: first column, window length (0 = not staged); stats
-    int window_max = 0;        // widest window any chunk stages in LDS (floats)
+    int staged_single = 0;     // TILED: chunks whose whole column span is staged in one pass
+    int staged_full = 0;       // TILED: chunks staged completely (any number of passes)
 };
 
 }  // namespace spmv

@@ -41,6 +41,8 @@ def main():
             cache[key] = (w, d_rp, d_ci, d_va, d_x, d_y)
         w, d_rp, d_ci, d_va, d_x, d_y = cache[key]
         os.environ.update(e.get("env", {}))
+        if "lib" in e:          # A/B between builds of the library inside one process
+            capi.use_library(ROOT / e["lib"])
         A = capi.CsrMatrix.from_device(w.rows, w.cols, d_rp, d_ci, d_va)
         B = W.algorithmic_bytes(w.rows, w.cols, w.nnz)
         for vname in e["variants"]:
@@ -48,7 +50,7 @@ def main():
             A.plan(v)
             A.time(v, d_x, d_y, 3)
             ms = min(A.time(v, d_x, d_y, e.get("iters", 30)) for _ in range(3))
-            print(json.dumps(dict(dist=e["dist"], band=e["band"], rows=rows, variant=vname, env=e.get("env", {}),
+            print(json.dumps(dict(dist=e["dist"], band=e["band"], rows=rows, variant=vname, env=e.get("env", {}), lib=e.get("lib", ""),
                                   ms=round(ms, 4), GBs=round(B / ms / 1e6, 1), pct=round(B / ms / 1e6 / 80, 2))), flush=True)
         A.close()
 

@@ -152,6 +152,51 @@ __global__ __launch_bounds__(BLK, 8) void k_win(const int* __restrict__ col, con
     }
 }
 
+// stage 4: window wider than the LDS region -> NPASS passes of REGION floats, predicated LDS gathers
+template <int BLK>
+__global__ __launch_bounds__(BLK, 8) void k_winp(const int* __restrict__ col, const float* __restrict__ val, const float* __restrict__ x,
+                                                 float* __restrict__ y, int per_row, int band, int64_t cols) {
+    constexpr int NPT = 16, V = 4, T = BLK * NPT, REGION = BLK * 18;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * T;
+    const i4* c4 = reinterpret_cast<const i4*>(col + base);
+    const f4* v4 = reinterpret_cast<const f4*>(val + base);
+    i4 cc[V]; f4 vv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { cc[j] = __builtin_nontemporal_load(&c4[j * BLK + tid]); vv[j] = __builtin_nontemporal_load(&v4[j * BLK + tid]); }
+    const int64_t r0 = base / per_row; const int nrows = T / per_row;
+    int64_t w0 = r0 - band / 2; if (w0 < 0) w0 = 0; w0 &= ~3ll;
+    int64_t w1 = r0 + nrows + band / 2 + 4; if (w1 > cols) w1 = cols;
+    const int wlen = (int)(w1 - w0);
+    const int npass = (wlen + REGION - 1) / REGION;
+    f4 xv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) xv[j] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < npass; ++p) {
+        const int off = p * REGION;
+        const int len = (wlen - off) < REGION ? (wlen - off) : REGION;
+        for (int i = tid * 4; i < len; i += BLK * 4) *reinterpret_cast<f4*>(smem + i) = *reinterpret_cast<const f4*>(x + w0 + off + i);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { unsigned o = (unsigned)(cc[j][q] - (int)w0 - off); if (o < (unsigned)len) xv[j][q] = smem[o]; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int p0 = pad_idx((j * BLK + tid) * 4);
+        smem[p0] = vv[j][0] * xv[j][0]; smem[p0 + 1] = vv[j][1] * xv[j][1]; smem[p0 + 2] = vv[j][2] * xv[j][2]; smem[p0 + 3] = vv[j][3] * xv[j][3];
+    }
+    __syncthreads();
+    for (int r = tid; r < nrows; r += BLK) {
+        float acc = 0.f;
+        for (int i = r * per_row; i < (r + 1) * per_row; ++i) acc += smem[pad_idx(i)];
+        y[r0 + r] = acc;
+    }
+}
+
 template <typename F>
 float timeit(F f, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -192,6 +237,11 @@ int main(int argc, char** argv) {
     RUN("lds_reduce", 16, (k_lds_reduce<16, false><<<nnz / (BS * 16), BS>>>(col, val, x, y, per_row)), bytes_alg)
     RUN("lds_reduce nt", 8, (k_lds_reduce<8, true><<<nnz / (BS * 8), BS>>>(col, val, x, y, per_row)), bytes_alg)
     RUN("lds_reduce nt", 16, (k_lds_reduce<16, true><<<nnz / (BS * 16), BS>>>(col, val, x, y, per_row)), bytes_alg)
+    if (band <= 300000) {
+#define RUNP(BLK, name) { size_t lds = (size_t)BLK * 18 * 4; CK(hipFuncSetAttribute((const void*)&k_winp<BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        RUN(name, BLK, (k_winp<BLK><<<nnz / (BLK * 16), BLK, lds>>>(col, val, x, y, per_row, (int)band, cols)), bytes_alg) }
+        RUNP(256, "win multipass blk") RUNP(512, "win multipass blk") RUNP(1024, "win multipass blk")
+    }
     if (band <= 16384) {
 #define RUNW(BLK, MODE, name) { size_t lds = (size_t)BLK * 18 * 4; CK(hipFuncSetAttribute((const void*)&k_win<BLK, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         if ((size_t)(band + BLK + 8) * 4 <= lds) RUN(name, BLK, (k_win<BLK, MODE><<<nnz / (BLK * 16), BLK, lds>>>(col, val, x, y, per_row, (int)band, cols)), bytes_alg) }
