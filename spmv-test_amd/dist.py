@@ -78,3 +78,101 @@ class ShardedSpmv:
     def step(self) -> torch.Tensor:
         self.multiply()
         return self.gather()
+
+
+class PipelinedSpmv:
+    """Block-cyclic row blocks with the all-gather of one block group overlapped with the multiply
+    of the next (SURVEY section 8e "Overlap").
+
+    The global row space is cut into ``S * world`` equal blocks of ``sub_rows`` rows; rank p owns
+    blocks ``s * world + p`` for s = 0..S-1.  Group s (one block per rank) is contiguous in the
+    natural row order, so ONE in-place all-gather per group lands it in ``y_full`` with no
+    permutation copy:  y_full[(s*world + p)*sub_rows : ...] is rank p's slot of group s.
+    A step issues, for s = 0..S-1: the local product of block s on the compute stream, then --
+    on a side stream that waits for that product only -- the all-gather of group s; RCCL moves
+    group s over xGMI while the CUs multiply block s+1.  S = 1 degenerates to the plain
+    multiply-then-gather.
+
+    ``local_spmvs[s](x_full, y_slot)`` enqueues the product of this rank's s-th block on the
+    CURRENT stream (the product binds ``CsrMatrix.run`` of one handle per block).
+    """
+
+    def __init__(self, S: int, sub_rows: int, cols: int, local_spmvs, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if len(local_spmvs) != S:
+            raise ValueError("need one local product per owned block")
+        self.S, self.sub_rows, self.cols = S, sub_rows, cols
+        self.rows = S * self.world * sub_rows
+        self.local_spmvs = list(local_spmvs)
+        self.device = torch.device(device)
+        self.x = torch.zeros(cols, dtype=torch.float32, device=device)
+        self.y_full = torch.zeros(self.rows, dtype=torch.float32, device=device)
+        self.cuda = self.device.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self._pending = []
+
+    def owned_blocks(self):
+        """Global block ids this rank owns, in the order of ``local_spmvs``."""
+        return [s * self.world + self.rank for s in range(self.S)]
+
+    def block_rows(self, s: int):
+        b = s * self.world + self.rank
+        return b * self.sub_rows, (b + 1) * self.sub_rows
+
+    def broadcast_x(self, src: int = 0) -> None:
+        if self.cuda and dist.get_backend(self.group) != "nccl":
+            host = self.x.cpu()
+            dist.broadcast(host, src=src, group=self.group)
+            self.x.copy_(host)
+        else:
+            dist.broadcast(self.x, src=src, group=self.group)
+
+    def _group_view(self, s: int):
+        n = self.world * self.sub_rows
+        return self.y_full[s * n:(s + 1) * n]
+
+    def _gather_group(self, s: int):
+        grp = self._group_view(s)
+        mine = grp[self.rank * self.sub_rows:(self.rank + 1) * self.sub_rows]
+        if self.world == 1:
+            return None
+        backend = dist.get_backend(self.group)
+        if self.cuda and backend != "nccl":      # rehearsal: gloo ranks sharing one GPU, via the host
+            host = torch.empty(grp.shape, dtype=torch.float32)
+            dist.all_gather_into_tensor(host, mine.cpu(), group=self.group)
+            grp.copy_(host)
+            return None
+        src = mine if self.cuda else mine.clone()
+        return dist.all_gather_into_tensor(grp, src, group=self.group, async_op=True)
+
+    def step(self) -> torch.Tensor:
+        """One y = A x: S products, S overlapped all-gathers; returns after everything is ENQUEUED
+        with the current stream ordered behind the last gather (so the next step, or a reader of
+        y_full on this stream, sees the complete vector)."""
+        if not self.cuda:
+            for s in range(self.S):
+                a, b = self.block_rows(s)
+                self.local_spmvs[s](self.x, self.y_full[a:b])
+                w = self._gather_group(s)
+                if w is not None:
+                    w.wait()
+            return self.y_full
+        compute = torch.cuda.current_stream(self.device)
+        works = []
+        for s in range(self.S):
+            a, b = self.block_rows(s)
+            self.local_spmvs[s](self.x, self.y_full[a:b])
+            if self.world > 1:
+                ev = torch.cuda.Event()
+                ev.record(compute)
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ev)          # gather s starts when product s is done
+                    works.append(self._gather_group(s))
+        for w in works:
+            if w is not None:
+                w.wait()                                     # orders the CURRENT stream behind the collective
+        if self.world > 1:
+            compute.wait_stream(self.comm_stream)
+        return self.y_full

@@ -14,14 +14,18 @@ void run_csr(int M, int N, float *A_host, float *X_host, float *Y_host, int vari
     spmv_csr_t *csr = nullptr;
     SPMV_CHECK(spmv_csr_from_dense_host(M, N, A_host, nullptr, &csr));
     float ms = 0.0f;
-    TIME_KERNEL(spmv_csr_run_host(csr, variant, X_host, Y_host, &ms), ms);
+    SPMV_CHECK(spmv_csr_run_host(csr, variant, X_host, Y_host, &ms));
+    // reference format: "<stringified kernel call> took <ms> ms" (kernel.hpp:44)
+    std::cout << "spmv_csr_run<" << spmv_variant_name(variant) << ">(rows=" << N << ", cols=" << M << ") took " << ms
+              << " ms" << std::endl;
     SPMV_CHECK(spmv_csr_destroy(csr));
 }
 
 void run_dense(int M, int N, float *A_host, float *X_host, float *Y_host, int mode)
 {
     float ms = 0.0f;
-    TIME_KERNEL(spmv_dense_gemv_host(M, N, A_host, X_host, Y_host, mode, &ms), ms);
+    SPMV_CHECK(spmv_dense_gemv_host(M, N, A_host, X_host, Y_host, mode, &ms));
+    std::cout << "spmv_dense_gemv<mode " << mode << ">(M=" << M << ", N=" << N << ") took " << ms << " ms" << std::endl;
 }
 
 [[noreturn]] void bad_version(const char *name, int version)

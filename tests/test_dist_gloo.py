@@ -71,3 +71,53 @@ def test_two_rank_row_block_exchange(built, balanced):
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert [r[1] for r in res] == [True, True]
     assert all(r[2] == (not balanced) for r in res)      # equal rows -> in-place gather path
+
+
+def _worker_pipe(rank, world, port, S, q):
+    import __graft_entry__ as ge
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg, orc = ge.load_package(), ge.load_oracle()
+        W = pkg.workloads
+        sub = W.BLOCK_ROWS
+        w = W.Workload("t", S * world * sub, S * world * sub, "mixed", 16, band=4096)
+        blocks = []
+        for s in range(S):
+            b = s * world + rank
+            r0, r1 = b * sub, (b + 1) * sub
+            rp = W.row_ptr(w, r0, sub)
+            ci, va = orc.synth_fill(w.seed, r0, r1, w.rows, w.cols, w.band, rp)
+            blocks.append((rp, ci, va))
+
+        def make(s):
+            rp, ci, va = blocks[s]
+            return lambda x, y: y.copy_(torch.from_numpy(orc.spmv(rp, ci, va, x.numpy())))
+
+        sh = pkg.dist.PipelinedSpmv(S, sub, w.cols, [make(s) for s in range(S)], torch.device("cpu"))
+        assert sh.owned_blocks() == [s * world + rank for s in range(S)]
+        if rank == 0:
+            sh.x.copy_(torch.from_numpy(orc.synth_x(w.seed, 0, w.cols)))
+        sh.broadcast_x(0)
+        y = sh.step().numpy().copy()
+        rp_all = W.row_ptr(w)
+        ci_all, va_all = orc.synth_fill(w.seed, 0, w.rows, w.rows, w.cols, w.band, rp_all)
+        y_ref = orc.spmv(rp_all, ci_all, va_all, orc.synth_x(w.seed, 0, w.cols))
+        q.put((rank, bool(np.array_equal(y.view(np.uint32), y_ref.view(np.uint32)))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [1, 3])
+def test_two_rank_block_cyclic_pipelined_exchange(built, S):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipe, args=(r, 2, port, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    assert [r[1] for r in res] == [True, True]
