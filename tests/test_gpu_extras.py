@@ -1,0 +1,113 @@
+"""GPU (-m gpu): properties of the C ABI beyond plain parity -- graph capture, the N>1 exchange
+with real kernels (two gloo ranks sharing the one GPU of the test box), plan selection."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from _util import assert_close_to_oracle, synth_problem
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_run_is_graph_capturable(pkg, oracle, gpu):
+    """include/spmv_hip.h promises spmv_csr_run allocates nothing and never synchronises."""
+    import torch
+    w = pkg.workloads.config("c4", band=4096, scale=1 / 64)
+    prob = synth_problem(pkg, oracle, gpu, w)
+    y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+    for name in ("adaptive", "tiled", "vector"):
+        v = pkg.capi.VARIANTS[name]
+        prob.A.plan(v)
+        prob.A.run(v, prob.d_x, prob.d_y)            # warm (module load, attribute set) outside capture
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                prob.A.run(v, prob.d_x, prob.d_y, stream=s)
+        prob.d_y.fill_(float("nan"))
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert_close_to_oracle(prob.d_y[:w.rows].cpu().numpy(), y64, mag, f"graph/{name}")
+
+
+def test_tiled_plan_picks_workgroup_size_from_the_data(pkg, oracle, gpu):
+    """Narrow band -> 256-thread workgroups, wider band -> larger ones; results stay within bound."""
+    import torch
+    W = pkg.workloads
+    for band in (1024, 6000, 14000, 100_000):
+        w = W.Workload("t", 4 * W.BLOCK_ROWS, 4 * W.BLOCK_ROWS, "const", 16, band=band)
+        prob = synth_problem(pkg, oracle, gpu, w)
+        y = prob.run(pkg.capi.TILED)
+        y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+        assert_close_to_oracle(y, y64, mag, f"band {band}")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank(rank, world, port, S, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg, orc = ge.load_package(), ge.load_oracle()
+        capi, W = pkg.capi, pkg.workloads
+        dev = torch.device("cuda:0")
+        sub = W.BLOCK_ROWS
+        w = W.Workload("t", S * world * sub, S * world * sub, "mixed", 16, band=8192)
+        handles = []
+        for s in range(S):
+            r0 = (s * world + rank) * sub
+            rp = W.row_ptr(w, r0, sub)
+            d_rp = torch.from_numpy(rp).to(dev)
+            d_ci = torch.empty(int(rp[-1]), dtype=torch.int32, device=dev)
+            d_va = torch.empty(int(rp[-1]), dtype=torch.float32, device=dev)
+            capi.synth_fill(w.seed, r0, sub, w.rows, w.cols, w.band, d_rp, d_ci, d_va)
+            A = capi.CsrMatrix.from_device(sub, w.cols, d_rp, d_ci, d_va)
+            A.plan(capi.TILED)
+            handles.append(A)
+        sh = pkg.dist.PipelinedSpmv(S, sub, w.cols, [(lambda h: lambda x, y: h.run(capi.TILED, x, y))(h) for h in handles], dev)
+        if rank == 0:
+            capi.synth_x(w.seed, 0, w.cols, sh.x)
+        sh.broadcast_x(0)
+        for _ in range(2):
+            y = sh.step()
+        torch.cuda.synchronize()
+        y = y.cpu().numpy()
+        rp_all = W.row_ptr(w)
+        ci, va = orc.synth_fill(w.seed, 0, w.rows, w.rows, w.cols, w.band, rp_all)
+        x = orc.synth_x(w.seed, 0, w.cols)
+        y64, mag = orc.spmv_f64(rp_all, ci, va, x)
+        err = np.abs(y.astype(np.float64) - y64)
+        q.put((rank, bool(np.all(err <= 1e-5 * mag + 1e-37))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_gpu_and_exchange_y(built, gpu):
+    """The N>1 path of bench.py with real HIP kernels: block-cyclic blocks, all-gather per group
+    (through gloo and the host here, RCCL on a multi-GPU node)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=10) for _ in range(2)) == [(0, True), (1, True)]
