@@ -182,53 +182,15 @@ __device__ __forceinline__ Segment make_segment(int t, int lb0, int64_t base, in
     return g;
 }
 
-// BLOCK/256 workgroups of BLOCK threads fill a CU to the same LDS bytes and waves; the second
-// launch-bounds argument keeps the kernel at <= 64 VGPRs so that they all fit (8 waves/SIMD).
-template <int BLOCK, bool TILED>
-__global__ __launch_bounds__(BLOCK, 8) void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int nchunks,
-                                                       const int32_t *__restrict__ row_ptr,
-                                                       const int32_t *__restrict__ col_idx,
-                                                       const float *__restrict__ vals,
-                                                       const float *__restrict__ x, float *__restrict__ y,
-                                                       const int32_t *__restrict__ chunk_lb,
-                                                       float *__restrict__ carry,
-                                                       const int32_t *__restrict__ win)
+// The stream of one chunk: 16 B per lane per load (1 KiB contiguous per wave instruction),
+// non-temporal (read once), all 8 loads issued back to back.
+template <int BLOCK, bool FULL_ONLY>
+__device__ __forceinline__ void load_stream(int64_t base, int n, int pad_col, const int32_t *__restrict__ col_idx,
+                                            const float *__restrict__ vals, int tid, i4 (&cc)[kNnzPerThread / 4],
+                                            f4 (&vv)[kNnzPerThread / 4])
 {
-    constexpr int kChunkT = chunk_of(BLOCK);
-    // one dynamic LDS region, used twice: first as the x window (TILED), then -- after the
-    // gathers have landed in registers -- as the product staging buffer.
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int2 long_seg[max_long(BLOCK)];  // {segment id, first product | end product << 16}
-    __shared__ int2 huge_seg[max_huge(BLOCK)];
-    __shared__ float wave_part[BLOCK / kWave];
-    __shared__ int long_count, huge_count;
-
-    const int tid = threadIdx.x;
-    const int c = xcd_chunk(blockIdx.x, nchunks);
-    const int64_t base = (int64_t)c * kChunkT;
-    const int n = (int)((nnz - base) < kChunkT ? (nnz - base) : kChunkT);
-    const int64_t lim = base + n;
-    if (tid == 0) { long_count = 0; huge_count = 0; }
-
-    // chunk metadata first: the row_ptr prefetch below depends on it
-    const int lb0 = chunk_lb[c], lb1 = chunk_lb[c + 1];
-    const int m = lb1 - lb0;
-    int w0 = 0, wlen = 0;
-    bool outside = false;
-    if (TILED) {
-        w0 = win[2 * c];
-        const int wl = win[2 * c + 1];
-        wlen = wl & (kOutsideBit - 1);
-        outside = (wl & kOutsideBit) != 0;
-    }
-
-    // ---- 1. stream the chunk: 16 B per lane per load (1 KiB contiguous per wave instruction),
-    //         non-temporal (read once), all loads issued before the first use
     constexpr int kVec = kNnzPerThread / 4;
-    i4 cc[kVec];
-    f4 vv[kVec];
-    const bool full = (n == kChunkT);
-    if (full) {
+    if (FULL_ONLY || n == chunk_of(BLOCK)) {
         const i4 *c4 = reinterpret_cast<const i4 *>(col_idx + base);
         const f4 *v4 = reinterpret_cast<const f4 *>(vals + base);
 #pragma unroll
@@ -245,140 +207,246 @@ __global__ __launch_bounds__(BLOCK, 8) void k_adaptive(int64_t rows, int64_t nnz
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool ok = (i0 + q) < n;
-                cc[j][q] = ok ? col_idx[base + i0 + q] : w0;
+                cc[j][q] = ok ? col_idx[base + i0 + q] : pad_col;
                 vv[j][q] = ok ? vals[base + i0 + q] : 0.0f;
             }
         }
     }
+}
 
-    // ---- 2. row pointers of this lane's first segment, in flight together with the stream
-    int32_t rb0 = 0, re0 = 0;
-    if (!TILED && tid <= m) {
-        rb0 = row_ptr[tid == 0 ? lb0 : lb0 + tid - 1];  // lb0 <= rows and row_ptr[rows] = nnz
-        re0 = tid == 0 ? 0 : row_ptr[lb0 + tid];
+// Chunk schedule over chunks [chunk0, chunk0 + nrun).
+// One-shot (PERSIST = false): workgroup b handles one chunk, xcd_chunk(b), and exits.
+// Persistent (PERSIST = true): the grid is sized to what is resident; the workgroups of XCD j walk
+// that XCD's contiguous chunk range with stride = workgroups on the XCD, and the stream loads of the
+// NEXT chunk are issued as soon as the products of the current one are in LDS, so every wave keeps
+// 8 KiB of HBM reads in flight while it reduces rows.  The host hands a persistent launch FULL
+// chunks only (the guarded tail loads cost registers); a trailing partial chunk gets a one-shot
+// launch of its own.
+struct Walk {
+    int c, end, stride;
+};
+
+__device__ __forceinline__ Walk first_chunk(bool persist, int bid, int grid, int nchunks)
+{
+    Walk w;
+    if (!persist) {
+        w.c = xcd_chunk(bid, nchunks);
+        w.end = w.c + 1;
+        w.stride = 1;
+        return w;
+    }
+    const int j = bid % kXcds, i = bid / kXcds;
+    const int q = nchunks / kXcds, rem = nchunks % kXcds;
+    const int start = j * q + (j < rem ? j : rem);
+    const int cnt = q + (j < rem ? 1 : 0);
+    w.stride = grid / kXcds + (j < grid % kXcds ? 1 : 0);  // workgroups that landed on this XCD label
+    w.c = start + i;
+    w.end = start + cnt;
+    return w;
+}
+
+// BLOCK/256 workgroups of BLOCK threads fill a CU to the same LDS bytes and waves.  One-shot: the
+// second launch-bounds argument keeps the kernel at <= 64 VGPRs (8 waves/SIMD).  Persistent: the
+// next chunk's 32 stream registers stay live through the reduction, so it is built for 80 VGPRs
+// (6 waves/SIMD; 4 for the 1024-thread workgroup, of which only one fits a CU then).
+__host__ __device__ constexpr int waves_per_simd(int block, bool persist) { return !persist ? 8 : (block == 1024 ? 4 : 6); }
+
+template <int BLOCK, bool TILED, bool PERSIST>
+__global__ __launch_bounds__(BLOCK, waves_per_simd(BLOCK, PERSIST))
+void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
+                                                       const int32_t *__restrict__ row_ptr,
+                                                       const int32_t *__restrict__ col_idx,
+                                                       const float *__restrict__ vals,
+                                                       const float *__restrict__ x, float *__restrict__ y,
+                                                       const int32_t *__restrict__ chunk_lb,
+                                                       float *__restrict__ carry,
+                                                       const int32_t *__restrict__ win)
+{
+    constexpr int kChunkT = chunk_of(BLOCK);
+    constexpr int kVec = kNnzPerThread / 4;
+    constexpr int kRegion = region_words(BLOCK);
+    // one dynamic LDS region, used twice: first as the x window (TILED), then -- after the
+    // gathers have landed in registers -- as the product staging buffer.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int2 long_seg[max_long(BLOCK)];  // {segment id, first product | end product << 16}
+    __shared__ int2 huge_seg[max_huge(BLOCK)];
+    __shared__ float wave_part[BLOCK / kWave];
+    __shared__ int long_count, huge_count;
+
+    const int tid = threadIdx.x;
+    Walk wk = first_chunk(PERSIST, blockIdx.x, gridDim.x, nrun);
+    if (wk.c >= wk.end) return;
+    wk.c += chunk0;
+    wk.end += chunk0;
+
+    i4 cc[kVec];
+    f4 vv[kVec];
+    {
+        const int64_t b0 = (int64_t)wk.c * kChunkT;
+        const int n0 = (int)((nnz - b0) < kChunkT ? (nnz - b0) : kChunkT);
+        load_stream<BLOCK, PERSIST>(b0, n0, TILED ? win[2 * wk.c] : 0, col_idx, vals, tid, cc, vv);
     }
 
-    // ---- 3. gather x: from LDS where the plan staged a window, else through L1/L2
-    constexpr int kRegion = region_words(BLOCK);
-    f4 xv[kVec];
-    if (TILED && wlen > 0) {
-        // ceil(wlen / kRegion) passes (one for a chunk whose column span fits the region): stage a
-        // slice of x, gather the nonzeros whose column lies in it.  Columns the plan left outside
-        // the staged range come straight from global memory (issued first).
-#pragma unroll
-        for (int j = 0; j < kVec; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xv[j][q] = 0.0f;
-        if (outside) {
+    for (;;) {
+        const int c = wk.c;
+        const int64_t base = (int64_t)c * kChunkT;
+        const int n = (int)((nnz - base) < kChunkT ? (nnz - base) : kChunkT);
+        const int64_t lim = base + n;
+        if (tid == 0) { long_count = 0; huge_count = 0; }
+
+        const int lb0 = chunk_lb[c], lb1 = chunk_lb[c + 1];
+        const int m = lb1 - lb0;
+        int w0 = 0, wlen = 0;
+        bool outside = false;
+        if (TILED) {
+            w0 = win[2 * c];
+            const int wl = win[2 * c + 1];
+            wlen = wl & (kOutsideBit - 1);
+            outside = (wl & kOutsideBit) != 0;
+        }
+
+        // ---- row pointers of this lane's first segment, in flight together with the stream
+        //      (ADAPTIVE only: TILED has no registers to spare for them)
+        int32_t rb0 = 0, re0 = 0;
+        if (!TILED && tid <= m) {
+            rb0 = row_ptr[tid == 0 ? lb0 : lb0 + tid - 1];  // lb0 <= rows and row_ptr[rows] = nnz
+            re0 = tid == 0 ? 0 : row_ptr[lb0 + tid];
+        }
+
+        // ---- gather x: from LDS where the plan staged a window, else through L1/L2
+        f4 xv[kVec];
+        if (TILED && wlen > 0) {
+            // ceil(wlen / kRegion) passes (one for a chunk whose column span fits the region):
+            // stage a slice of x, gather the nonzeros whose column lies in it.  Columns the plan
+            // left outside the staged range come straight from global memory (issued first).
 #pragma unroll
             for (int j = 0; j < kVec; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if ((unsigned)(cc[j][q] - w0) >= (unsigned)wlen) xv[j][q] = x[cc[j][q]];
-        }
-        for (int off = 0; off < wlen; off += kRegion) {
-            const int len = (wlen - off) < kRegion ? (wlen - off) : kRegion;
-            const int64_t g0 = (int64_t)w0 + off;
-            for (int i = tid * 4; i < len; i += BLOCK * 4) {
-                if (g0 + i + 3 < cols) {
-                    *reinterpret_cast<f4 *>(smem + i) = *reinterpret_cast<const f4 *>(x + g0 + i);
-                } else {
+                for (int q = 0; q < 4; ++q) xv[j][q] = 0.0f;
+            if (outside) {
+#pragma unroll
+                for (int j = 0; j < kVec; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (g0 + i + q < cols) smem[i + q] = x[g0 + i + q];
-                }
+                        if ((unsigned)(cc[j][q] - w0) >= (unsigned)wlen) xv[j][q] = x[cc[j][q]];
             }
-            __syncthreads();
+            for (int off = 0; off < wlen; off += kRegion) {
+                const int len = (wlen - off) < kRegion ? (wlen - off) : kRegion;
+                const int64_t g0 = (int64_t)w0 + off;
+                for (int i = tid * 4; i < len; i += BLOCK * 4) {
+                    if (g0 + i + 3 < cols) {
+                        *reinterpret_cast<f4 *>(smem + i) = *reinterpret_cast<const f4 *>(x + g0 + i);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (g0 + i + q < cols) smem[i + q] = x[g0 + i + q];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < kVec; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned o = (unsigned)(cc[j][q] - w0 - off);
+                        if (o < (unsigned)len) xv[j][q] = smem[o];
+                    }
+                __syncthreads();  // every gather has its value before the slice is overwritten
+            }
+        } else {
 #pragma unroll
             for (int j = 0; j < kVec; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned o = (unsigned)(cc[j][q] - w0 - off);
-                    if (o < (unsigned)len) xv[j][q] = smem[o];
+                for (int q = 0; q < 4; ++q) xv[j][q] = x[cc[j][q]];
+        }
+
+        // ---- stage the products (padded one word per 32: lane-per-row reads spread over banks)
+#pragma unroll
+        for (int j = 0; j < kVec; ++j) {
+            const int p0 = pad_idx((j * BLOCK + tid) * 4);  // i0 % 4 == 0: never straddles a pad slot
+            smem[p0] = vv[j][0] * xv[j][0];
+            smem[p0 + 1] = vv[j][1] * xv[j][1];
+            smem[p0 + 2] = vv[j][2] * xv[j][2];
+            smem[p0 + 3] = vv[j][3] * xv[j][3];
+        }
+
+        // ---- the next chunk's stream, into the registers the products just left
+        const int cn = c + wk.stride;
+        const bool more = PERSIST && cn < wk.end;
+        if (more) {
+            const int64_t bn = (int64_t)cn * kChunkT;
+            const int nn = (int)((nnz - bn) < kChunkT ? (nnz - bn) : kChunkT);
+            load_stream<BLOCK, PERSIST>(bn, nn, TILED ? win[2 * cn] : 0, col_idx, vals, tid, cc, vv);
+        }
+        __syncthreads();
+
+        // ---- short segments: one lane each, sequential (the oracle's order); longer ones are
+        //      queued in LDS with their bounds so that the later phases touch no global metadata
+        for (int t = tid; t <= m; t += BLOCK) {
+            int32_t rb, re;
+            if (!TILED && t == tid) { rb = rb0; re = re0; }
+            else { rb = row_ptr[t == 0 ? lb0 : lb0 + t - 1]; re = t == 0 ? 0 : row_ptr[lb0 + t]; }
+            const Segment g = make_segment(t, lb0, base, lim, rb, re, y, carry, c);
+            if (g.e - g.s <= kShortSeg) {
+                float acc = 0.0f;
+                int i = g.s;
+                for (; i + 3 < g.e; i += 4) {
+                    const float a0 = smem[pad_idx(i)], a1 = smem[pad_idx(i + 1)], a2 = smem[pad_idx(i + 2)],
+                                a3 = smem[pad_idx(i + 3)];
+                    acc = (((acc + a0) + a1) + a2) + a3;
                 }
-            __syncthreads();  // every gather has its value before the slice is overwritten
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < kVec; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xv[j][q] = x[cc[j][q]];
-    }
-
-    // ---- 4. stage the products (padded one word per 32: lane-per-row reads spread over banks)
-#pragma unroll
-    for (int j = 0; j < kVec; ++j) {
-        const int p0 = pad_idx((j * BLOCK + tid) * 4);  // i0 % 4 == 0: never straddles a pad slot
-        smem[p0] = vv[j][0] * xv[j][0];
-        smem[p0 + 1] = vv[j][1] * xv[j][1];
-        smem[p0 + 2] = vv[j][2] * xv[j][2];
-        smem[p0 + 3] = vv[j][3] * xv[j][3];
-    }
-    __syncthreads();
-
-    // ---- 5. short segments: one lane each, sequential (the oracle's order); longer ones are
-    //         queued in LDS with their bounds so that phase 6 touches no global metadata
-    for (int t = tid; t <= m; t += BLOCK) {
-        int32_t rb, re;
-        if (!TILED && t == tid) { rb = rb0; re = re0; }
-        else { rb = row_ptr[t == 0 ? lb0 : lb0 + t - 1]; re = t == 0 ? 0 : row_ptr[lb0 + t]; }
-        const Segment g = make_segment(t, lb0, base, lim, rb, re, y, carry, c);
-        if (g.e - g.s <= kShortSeg) {
-            float acc = 0.0f;
-            int i = g.s;
-            for (; i + 3 < g.e; i += 4) {
-                const float a0 = smem[pad_idx(i)], a1 = smem[pad_idx(i + 1)], a2 = smem[pad_idx(i + 2)],
-                            a3 = smem[pad_idx(i + 3)];
-                acc = (((acc + a0) + a1) + a2) + a3;
+                for (; i < g.e; ++i) acc += smem[pad_idx(i)];
+                *g.dst = acc;
+            } else if (g.e - g.s <= kHugeSeg) {
+                const int slot = atomicAdd(&long_count, 1);
+                long_seg[slot] = make_int2(t, g.s | (g.e << 16));  // s < 2^14, e <= 2^14
+            } else {
+                const int slot = atomicAdd(&huge_count, 1);
+                huge_seg[slot] = make_int2(t, g.s | (g.e << 16));
             }
-            for (; i < g.e; ++i) acc += smem[pad_idx(i)];
-            *g.dst = acc;
-        } else if (g.e - g.s <= kHugeSeg) {
-            const int slot = atomicAdd(&long_count, 1);
-            long_seg[slot] = make_int2(t, g.s | (g.e << 16));  // s < 2^14, e <= 2^14
-        } else {
-            const int slot = atomicAdd(&huge_count, 1);
-            huge_seg[slot] = make_int2(t, g.s | (g.e << 16));
-        }
-    }
-    __syncthreads();
-
-    // ---- 6. long segments: one kGroup-lane group each (BLOCK/kGroup in parallel), lanes stride
-    //         the segment, __shfl_down tree inside the group
-    const int nlong = long_count;
-    const int sub = tid & (kGroup - 1);
-    for (int i = tid / kGroup; i < nlong; i += BLOCK / kGroup) {
-        const int2 q = long_seg[i];
-        const int qe = (int)((unsigned)q.y >> 16);
-        float acc = 0.0f;
-        for (int k = (q.y & 0xffff) + sub; k < qe; k += kGroup) acc += smem[pad_idx(k)];
-#pragma unroll
-        for (int o = kGroup / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kGroup);
-        if (sub == 0) {
-            if (q.x == 0) carry[c] = acc;
-            else y[(int64_t)lb0 + q.x - 1] = acc;
-        }
-    }
-
-    // ---- 7. huge segments (a power-law row can fill the whole chunk): the whole workgroup
-    //         strides one segment, wavefront trees, then the per-wave partials in wave order
-    const int nhuge = huge_count;
-    for (int i = 0; i < nhuge; ++i) {
-        const int2 q = huge_seg[i];
-        const int qe = (int)((unsigned)q.y >> 16);
-        float acc = 0.0f;
-        for (int k = (q.y & 0xffff) + tid; k < qe; k += BLOCK) acc += smem[pad_idx(k)];
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
-        if ((tid & (kWave - 1)) == 0) wave_part[tid >> 6] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            float tot = 0.0f;
-            for (int w = 0; w < BLOCK / kWave; ++w) tot += wave_part[w];
-            if (q.x == 0) carry[c] = tot;
-            else y[(int64_t)lb0 + q.x - 1] = tot;
         }
         __syncthreads();
+
+        // ---- long segments: one kGroup-lane group each (BLOCK/kGroup in parallel), lanes stride
+        //      the segment, __shfl_down tree inside the group
+        const int nlong = long_count;
+        const int sub = tid & (kGroup - 1);
+        for (int i = tid / kGroup; i < nlong; i += BLOCK / kGroup) {
+            const int2 q = long_seg[i];
+            const int qe = (int)((unsigned)q.y >> 16);
+            float acc = 0.0f;
+            for (int k = (q.y & 0xffff) + sub; k < qe; k += kGroup) acc += smem[pad_idx(k)];
+#pragma unroll
+            for (int o = kGroup / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kGroup);
+            if (sub == 0) {
+                if (q.x == 0) carry[c] = acc;
+                else y[(int64_t)lb0 + q.x - 1] = acc;
+            }
+        }
+
+        // ---- huge segments (a power-law row can fill the whole chunk): the whole workgroup
+        //      strides one segment, wavefront trees, then the per-wave partials in wave order
+        const int nhuge = huge_count;
+        for (int i = 0; i < nhuge; ++i) {
+            const int2 q = huge_seg[i];
+            const int qe = (int)((unsigned)q.y >> 16);
+            float acc = 0.0f;
+            for (int k = (q.y & 0xffff) + tid; k < qe; k += BLOCK) acc += smem[pad_idx(k)];
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+            if ((tid & (kWave - 1)) == 0) wave_part[tid >> 6] = acc;
+            __syncthreads();
+            if (tid == 0) {
+                float tot = 0.0f;
+                for (int w = 0; w < BLOCK / kWave; ++w) tot += wave_part[w];
+                if (q.x == 0) carry[c] = tot;
+                else y[(int64_t)lb0 + q.x - 1] = tot;
+            }
+            __syncthreads();
+        }
+
+        if (!more) break;
+        __syncthreads();  // the region and the queues are reused by the next chunk
+        wk.c = cn;
     }
 }
 
@@ -422,6 +490,9 @@ static int build_plan(const spmv_csr &h, int block, bool windows, hipStream_t s,
 {
     free_plan(p);
     p.block = block;
+    // tuning knob SPMV_PERSIST=0|1, read when the plan is made (default 0: the persistent form
+    // needs 80 VGPRs -> 6 waves/SIMD, and lost 7-40 % against 8 waves/SIMD one-shot workgroups)
+    if (const char *e = getenv("SPMV_PERSIST")) p.persist = atoi(e) != 0;
     const int chunk = chunk_of(block);
     p.nchunks = (int)((h.nnz + chunk - 1) / chunk);
     if (single) *single = 0;
@@ -487,20 +558,53 @@ void destroy_plans(spmv_csr &h)
     free_plan(h.plan_tiled);
 }
 
-template <int BLOCK, bool TILED>
-static int launch_block(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
+static int resident_workgroups(int block, int waves_simd)
 {
-    // dynamic LDS: the product buffer; a staged x window is never wider (plan cap = region)
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    int per_cu = (waves_simd * 4 * kWave) / block;  // workgroups per CU by waves
+    if (per_cu < 1) per_cu = 1;
+    return cus * per_cu;
+}
+
+template <int BLOCK, bool TILED, bool PERSIST>
+static int launch_range(const spmv_csr &h, const ChunkPlan &p, int chunk0, int nrun, const float *x, float *y,
+                        hipStream_t s)
+{
+    if (nrun <= 0) return SPMV_OK;
+    // dynamic LDS: the product buffer; a staged x slice is never wider (plan cap = region)
     const size_t lds = sizeof(float) * (size_t)region_words(BLOCK);
     static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in (BLOCK = 1024)
     if (!attr_set) {
-        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_adaptive<BLOCK, TILED>),
+        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_adaptive<BLOCK, TILED, PERSIST>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_adaptive<BLOCK, TILED>), dim3(p.nchunks), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols,
-                       p.nchunks, h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win);
+    int grid = nrun;
+    if (PERSIST) {
+        const int res = resident_workgroups(BLOCK, waves_per_simd(BLOCK, true));
+        if (grid > res) grid = res;
+    }
+    hipLaunchKernelGGL((k_adaptive<BLOCK, TILED, PERSIST>), dim3(grid), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols,
+                       chunk0, nrun, h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win);
     return check_launch("k_adaptive");
+}
+
+template <int BLOCK, bool TILED>
+static int launch_either(bool persist, const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
+{
+    if (!persist) return launch_range<BLOCK, TILED, false>(h, p, 0, p.nchunks, x, y, s);
+    // persistent launch over the full chunks, one-shot launch for a trailing partial chunk
+    const int nfull = (int)(h.nnz / chunk_of(BLOCK));
+    int rc = launch_range<BLOCK, TILED, true>(h, p, 0, nfull, x, y, s);
+    if (rc == SPMV_OK && p.nchunks > nfull) rc = launch_range<BLOCK, TILED, false>(h, p, nfull, p.nchunks - nfull, x, y, s);
+    return rc;
 }
 
 int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s)
@@ -515,11 +619,12 @@ int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hip
         SPMV_HIP_TRY(hipMemsetAsync(y, 0, sizeof(float) * (size_t)h.rows, s));
         return SPMV_OK;
     }
+    const bool persist = p.persist;
     int rc;
-    if (!tiled) rc = launch_block<256, false>(h, p, x, y, s);
-    else if (p.block == 256) rc = launch_block<256, true>(h, p, x, y, s);
-    else if (p.block == 512) rc = launch_block<512, true>(h, p, x, y, s);
-    else rc = launch_block<1024, true>(h, p, x, y, s);
+    if (!tiled) rc = launch_either<256, false>(persist, h, p, x, y, s);
+    else if (p.block == 256) rc = launch_either<256, true>(persist, h, p, x, y, s);
+    else if (p.block == 512) rc = launch_either<512, true>(persist, h, p, x, y, s);
+    else rc = launch_either<1024, true>(persist, h, p, x, y, s);
     if (rc) return rc;
     if (p.nchunks > 1) {
         hipLaunchKernelGGL(k_carry_fixup, dim3((p.nchunks - 1 + 255) / 256), dim3(256), 0, s, p.nchunks,

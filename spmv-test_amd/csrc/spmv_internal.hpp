@@ -34,6 +34,7 @@ struct ChunkPlan {
     int32_t *d_lb = nullptr;   // [nchunks+1] first row whose row_ptr >= c*chunk
     float *d_carry = nullptr;  // [nchunks]   partial sum of the row continued from chunk c-1
     int32_t *d_win = nullptr;  // [2*nchunks+2] TILED: first column, window length (0 = not staged); stats
+    bool persist = false;      // persistent software-pipelined launch (measured slower: DESIGN.md section 4)
     int staged_single = 0;     // TILED: chunks whose whole column span is staged in one pass
     int staged_full = 0;       // TILED: chunks staged completely (any number of passes)
 };
