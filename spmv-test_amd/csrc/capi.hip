@@ -93,23 +93,22 @@ int spmv_csr_create_host(int64_t rows, int64_t cols, int64_t nnz, const int32_t 
                   row_ptr[rows], (long long)nnz);
         return SPMV_ERR_INVALID;
     }
-    int32_t *d_rp = nullptr, *d_ci = nullptr;
-    float *d_v = nullptr;
-    const size_t n1 = nnz > 0 ? (size_t)nnz : 1;
-    SPMV_HIP_TRY(hipMalloc((void **)&d_rp, sizeof(int32_t) * ((size_t)rows + 1)));
-    SPMV_HIP_TRY(hipMalloc((void **)&d_ci, sizeof(int32_t) * n1));
-    SPMV_HIP_TRY(hipMalloc((void **)&d_v, sizeof(float) * n1));
-    SPMV_HIP_TRY(hipMemcpy(d_rp, row_ptr, sizeof(int32_t) * ((size_t)rows + 1), hipMemcpyHostToDevice));
+    DevPtr<int32_t> rp, ci;
+    DevPtr<float> va;
+    SPMV_HIP_TRY(rp.alloc((size_t)rows + 1));
+    SPMV_HIP_TRY(ci.alloc((size_t)nnz));
+    SPMV_HIP_TRY(va.alloc((size_t)nnz));
+    SPMV_HIP_TRY(hipMemcpy(rp.p, row_ptr, sizeof(int32_t) * ((size_t)rows + 1), hipMemcpyHostToDevice));
     if (nnz > 0) {
-        SPMV_HIP_TRY(hipMemcpy(d_ci, col_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
-        SPMV_HIP_TRY(hipMemcpy(d_v, vals, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+        SPMV_HIP_TRY(hipMemcpy(ci.p, col_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+        SPMV_HIP_TRY(hipMemcpy(va.p, vals, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
     }
     spmv_csr *h = new (std::nothrow) spmv_csr();
     if (!h) { set_error("out of host memory"); return SPMV_ERR_INVALID; }
     h->rows = rows; h->cols = cols; h->nnz = nnz;
-    h->d_row_ptr = d_rp; h->d_col_idx = d_ci; h->d_vals = d_v;
     h->owns_arrays = true;
-    SPMV_HIP_TRY(hipGetDevice(&h->device));
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+    h->d_row_ptr = rp.release(); h->d_col_idx = ci.release(); h->d_vals = va.release();
     *out = h;
     return SPMV_OK;
 }

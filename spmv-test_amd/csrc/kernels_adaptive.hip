@@ -28,6 +28,7 @@
 //     floats at the same LDS bytes per wave; the plan picks the smallest workgroup whose region
 //     covers the windows of >= 90 % of the chunks, and a chunk whose window does not fit
 //     gathers from global memory.
+#include <atomic>
 #include <cstdlib>
 #include "spmv_internal.hpp"
 
@@ -580,11 +581,11 @@ static int launch_range(const spmv_csr &h, const ChunkPlan &p, int chunk0, int n
     if (nrun <= 0) return SPMV_OK;
     // dynamic LDS: the product buffer; a staged x slice is never wider (plan cap = region)
     const size_t lds = sizeof(float) * (size_t)region_words(BLOCK);
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in (BLOCK = 1024)
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};  // > 64 KiB of dynamic LDS needs the opt-in (BLOCK = 1024)
+    if (!attr_set.load(std::memory_order_acquire)) {
         SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_adaptive<BLOCK, TILED, PERSIST>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     int grid = nrun;
     if (PERSIST) {

@@ -105,45 +105,44 @@ static int check_launch(const char *what)
 int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out)
 {
     int rc;
-    int32_t *d_counts = nullptr, *d_total = nullptr, *d_row_ptr = nullptr, *d_col = nullptr;
-    float *d_val = nullptr;
+    DevPtr<int32_t> counts, total, row_ptr, col;
+    DevPtr<float> val;
     const size_t ncnt = (size_t)N * kSlabs;
-    SPMV_HIP_TRY(hipMalloc((void **)&d_counts, sizeof(int32_t) * (ncnt ? ncnt : 1)));
-    SPMV_HIP_TRY(hipMalloc((void **)&d_total, sizeof(int32_t)));
-    SPMV_HIP_TRY(hipMalloc((void **)&d_row_ptr, sizeof(int32_t) * ((size_t)N + 1)));
-    SPMV_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(int32_t), s));
-    const dim3 grid((N + kBlock - 1) / kBlock ? (N + kBlock - 1) / kBlock : 1, kSlabs);
+    SPMV_HIP_TRY(counts.alloc(ncnt));
+    SPMV_HIP_TRY(total.alloc(1));
+    SPMV_HIP_TRY(row_ptr.alloc((size_t)N + 1));
+    SPMV_HIP_TRY(hipMemsetAsync(total.p, 0, sizeof(int32_t), s));
+    const int gx = (N + kBlock - 1) / kBlock;
+    const dim3 grid(gx ? gx : 1, kSlabs);
     if (N > 0) {
-        hipLaunchKernelGGL(k_dense_count, grid, dim3(kBlock), 0, s, M, N, d_A, d_counts);
+        hipLaunchKernelGGL(k_dense_count, grid, dim3(kBlock), 0, s, M, N, d_A, counts.p);
         if ((rc = check_launch("k_dense_count"))) return rc;
-        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, (int64_t)ncnt, d_counts, d_total);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, (int64_t)ncnt, counts.p, total.p);
         if ((rc = check_launch("k_exclusive_scan"))) return rc;
     }
     hipLaunchKernelGGL(k_row_ptr_from_offsets, dim3((N + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, N,
-                       d_counts, d_total, d_row_ptr);
+                       counts.p, total.p, row_ptr.p);
     if ((rc = check_launch("k_row_ptr_from_offsets"))) return rc;
     int32_t nnz = 0;
-    SPMV_HIP_TRY(hipMemcpyAsync(&nnz, d_total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipMemcpyAsync(&nnz, total.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SPMV_HIP_TRY(hipStreamSynchronize(s));
-    SPMV_HIP_TRY(hipMalloc((void **)&d_col, sizeof(int32_t) * ((size_t)nnz ? (size_t)nnz : 1)));
-    SPMV_HIP_TRY(hipMalloc((void **)&d_val, sizeof(float) * ((size_t)nnz ? (size_t)nnz : 1)));
+    SPMV_HIP_TRY(col.alloc((size_t)nnz));
+    SPMV_HIP_TRY(val.alloc((size_t)nnz));
     if (N > 0 && nnz > 0) {
-        hipLaunchKernelGGL(k_dense_fill, grid, dim3(kBlock), 0, s, M, N, d_A, d_counts, d_col, d_val);
+        hipLaunchKernelGGL(k_dense_fill, grid, dim3(kBlock), 0, s, M, N, d_A, counts.p, col.p, val.p);
         if ((rc = check_launch("k_dense_fill"))) return rc;
     }
     SPMV_HIP_TRY(hipStreamSynchronize(s));
-    SPMV_HIP_TRY(hipFree(d_counts));
-    SPMV_HIP_TRY(hipFree(d_total));
 
     spmv_csr *h = new spmv_csr();
     h->rows = N;
     h->cols = M;
     h->nnz = nnz;
-    h->d_row_ptr = d_row_ptr;
-    h->d_col_idx = d_col;
-    h->d_vals = d_val;
     h->owns_arrays = true;
-    SPMV_HIP_TRY(hipGetDevice(&h->device));
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+    h->d_row_ptr = row_ptr.release();
+    h->d_col_idx = col.release();
+    h->d_vals = val.release();
     *out = h;
     return SPMV_OK;
 }

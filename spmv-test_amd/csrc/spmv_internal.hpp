@@ -17,6 +17,18 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (e__ != hipSuccess) return ::spmv::hip_fail(e__, #call, __FILE__, __LINE__); \
     } while (0)
 
+// Device allocation that frees itself unless release()d into a handle.
+template <typename T>
+struct DevPtr {
+    T *p = nullptr;
+    DevPtr() = default;
+    DevPtr(const DevPtr &) = delete;
+    DevPtr &operator=(const DevPtr &) = delete;
+    ~DevPtr() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1)); }
+    T *release() { T *q = p; p = nullptr; return q; }
+};
+
 // ---- geometry constants ----------------------------------------------------
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kBlock = 256;        // 4 waves: one per SIMD of a CU

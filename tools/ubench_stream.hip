@@ -76,6 +76,30 @@ __global__ __launch_bounds__(BS) void k_gather(const int* __restrict__ col, cons
     out[(int64_t)blockIdx.x * BS + threadIdx.x] = acc;
 }
 
+// stage 1b: gather with non-temporal / different-scope loads of x (does the fetch granule change?)
+template <int MODE>
+__global__ __launch_bounds__(BS) void k_gather_x(const int* __restrict__ col, const float* __restrict__ val, const float* __restrict__ x, float* __restrict__ out) {
+    constexpr int V = 4;
+    const int64_t base = (int64_t)blockIdx.x * BS * 16;
+    const i4* c4 = reinterpret_cast<const i4*>(col + base);
+    const f4* v4 = reinterpret_cast<const f4*>(val + base);
+    i4 cc[V]; f4 vv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { cc[j] = __builtin_nontemporal_load(&c4[j * BS + threadIdx.x]); vv[j] = __builtin_nontemporal_load(&v4[j * BS + threadIdx.x]); }
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float xv;
+            if (MODE == 0) xv = x[cc[j][q]];
+            else if (MODE == 1) xv = __builtin_nontemporal_load(&x[cc[j][q]]);
+            else xv = __hip_atomic_load(&x[cc[j][q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc += vv[j][q] * xv;
+        }
+    out[(int64_t)blockIdx.x * BS + threadIdx.x] = acc;
+}
+
 // stage 2: + products through LDS, thread-per-row sequential reduce (rows of 16), y store
 __device__ __forceinline__ int pad_idx(int i) { return i + (i >> 5); }
 template <int NPT, bool NT>
@@ -233,6 +257,9 @@ int main(int argc, char** argv) {
     RUN("gather", 16, (k_gather<16, false><<<nnz / (BS * 16), BS>>>(col, val, x, y)), bytes_alg)
     RUN("gather nt", 8, (k_gather<8, true><<<nnz / (BS * 8), BS>>>(col, val, x, y)), bytes_alg)
     RUN("gather nt", 16, (k_gather<16, true><<<nnz / (BS * 16), BS>>>(col, val, x, y)), bytes_alg)
+    RUN("gather_x plain", 16, (k_gather_x<0><<<nnz / (BS * 16), BS>>>(col, val, x, y)), bytes_alg)
+    RUN("gather_x nt", 16, (k_gather_x<1><<<nnz / (BS * 16), BS>>>(col, val, x, y)), bytes_alg)
+    RUN("gather_x sc1", 16, (k_gather_x<2><<<nnz / (BS * 16), BS>>>(col, val, x, y)), bytes_alg)
     RUN("lds_reduce", 8, (k_lds_reduce<8, false><<<nnz / (BS * 8), BS>>>(col, val, x, y, per_row)), bytes_alg)
     RUN("lds_reduce", 16, (k_lds_reduce<16, false><<<nnz / (BS * 16), BS>>>(col, val, x, y, per_row)), bytes_alg)
     RUN("lds_reduce nt", 8, (k_lds_reduce<8, true><<<nnz / (BS * 8), BS>>>(col, val, x, y, per_row)), bytes_alg)
