@@ -9,6 +9,7 @@
 set -e
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 50 --warmup 5 --no-extras --no-cpu-baseline"

@@ -19,6 +19,14 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def newest(pattern):
+    """gpurun_out/ accumulates across calls: take the most recent file that matches."""
+    files = sorted(glob.glob(str(pattern)), key=lambda f: Path(f).stat().st_mtime)
+    if not files:
+        raise SystemExit(f"no file matches {pattern}")
+    return files[-1]
+
+
 def means(path):
     acc = defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -31,12 +39,12 @@ def main():
     src = ROOT / "gpurun_out" / f"prof_{tag}"
     dst = ROOT / "profiles"
     dst.mkdir(exist_ok=True)
-    stats = glob.glob(str(src / "trace" / "*" / "*_kernel_stats.csv"))[0]
+    stats = newest(src / "trace" / "*" / "*_kernel_stats.csv")
     shutil.copy(stats, dst / f"{tag}_kernel_stats.csv")
-    fetch = means(glob.glob(str(src / "fetch" / "*" / "*_counter_collection.csv"))[0])
-    write = means(glob.glob(str(src / "write" / "*" / "*_counter_collection.csv"))[0])
-    cal_f = means(glob.glob(str(src / "cal_fetch" / "*" / "*_counter_collection.csv"))[0])
-    cal_w = means(glob.glob(str(src / "cal_write" / "*" / "*_counter_collection.csv"))[0])
+    fetch = means(newest(src / "fetch" / "*" / "*_counter_collection.csv"))
+    write = means(newest(src / "write" / "*" / "*_counter_collection.csv"))
+    cal_f = means(newest(src / "cal_fetch" / "*" / "*_counter_collection.csv"))
+    cal_w = means(newest(src / "cal_write" / "*" / "*_counter_collection.csv"))
     bench = json.loads((src / "bench_trace.json").read_text().strip().splitlines()[-1])
 
     # calibration: k_stream<16,false> reads exactly 2^31 B (2^28 col_idx + 2^28 vals) and writes 2^26 B
