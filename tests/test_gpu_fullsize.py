@@ -8,6 +8,24 @@ from _util import RTOL
 pytestmark = pytest.mark.gpu
 
 
+# ---- configs 2 and 3 at FULL size: the oracle walks them in a few seconds, so every row is checked ----
+@pytest.mark.parametrize("name,band", [("c2", 0), ("c2", 8192), ("c3", 0), ("c3", 8192)])
+def test_config_2_and_3_full_size_every_row(pkg, oracle, gpu, name, band):
+    """BASELINE configs[1] (1Mi^2, 16/row; the scalar thread-per-row kernel is its named variant) and
+    configs[2] (4Mi^2 power-law, mean 32; wave-per-row is its named variant): all variants, all rows."""
+    from _util import assert_close_to_oracle, synth_problem
+    w = pkg.workloads.config(name, band=band)
+    assert w.nnz == {"c2": 1 << 24, "c3": 1 << 27}[name]
+    prob = synth_problem(pkg, oracle, gpu, w)          # also checks the device generator bit for bit
+    y_seq = oracle.spmv(prob.row_ptr, prob.col_idx, prob.vals, prob.x, threads=8)
+    y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+    for vname, v in pkg.capi.VARIANTS.items():
+        y = prob.run(v)
+        if vname == "scalar":
+            assert np.array_equal(y.view(np.uint32), y_seq.view(np.uint32)), f"{w.name}: scalar not bit-identical"
+        assert_close_to_oracle(y, y64, mag, f"{w.name}/{vname}")
+
+
 @pytest.fixture(scope="module", params=[0, 1 << 16], ids=["uniform", "banded"])
 def c4(request, pkg, gpu):
     import torch
