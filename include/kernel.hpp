@@ -26,7 +26,7 @@ void tiling_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);
 void cublas_gemv_gpu(int M, int N, float *A, float *X, float *Y);                      // dense, split-M (vendor slot)
 void naive_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);       // dense, thread per output
 void csr_naive_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);   // SPMV_SCALAR
-void csr_tiling_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);  // SPMV_TILED
+void csr_tiling_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);  // tiled bitmap-CSR (spmv_tcsr_*)
 void wsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);   // 0 SPMV_WAVE, 1 SPMV_WAVE_PIPE
 void asp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);   // 0,1,2 SPMV_VECTOR
 void awsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);  // 0,1 SPMV_ADAPTIVE, 2 SPMV_TILED

@@ -140,6 +140,22 @@ SPMV_API int spmv_dense_gemv(int M, int N, const float *d_A, const float *d_x, f
 SPMV_API int spmv_dense_gemv_host(int M, int N, const float *A_host, const float *x_host, float *y_host,
                                   int mode, float *kernel_ms);
 
+/* ---- the reference's tiled bitmap-CSR format (dense-ish matrices, density > 1/32) -----
+ * replaces: TCSRMatrix (src/tcsr.cpp:5-38, src/include/tcsr.hpp:4-23) and csr_tiling_kernel
+ * with its launcher (src/kernels/csr_tiling.cu:24-166).  Same arrays, bit for bit: blk_idx
+ * (exclusive nonzero prefix per 32x32 block + sentinel), bitmaps (word = output column inside
+ * the block, bit = input row), vals (unpadded, bitmap order).  M and N must be multiples of 32
+ * (the reference asserts it, src/tester.cpp:9-10); anything else is SPMV_ERR_INVALID.
+ * Built on the device from the dense matrix; y[i] = sum_j x[j]*A[j*N+i] as everywhere. */
+typedef struct spmv_tcsr spmv_tcsr_t;
+SPMV_API int spmv_tcsr_from_dense_host(int M, int N, const float *A_host, void *stream, spmv_tcsr_t **out);
+SPMV_API int spmv_tcsr_from_dense_device(int M, int N, const float *d_A, void *stream, spmv_tcsr_t **out);
+SPMV_API int spmv_tcsr_sizes(const spmv_tcsr_t *h, int64_t *n_blk_idx, int64_t *n_bitmaps, int64_t *n_vals);
+SPMV_API int spmv_tcsr_download(const spmv_tcsr_t *h, int32_t *blk_idx, uint32_t *bitmaps, float *vals);
+SPMV_API int spmv_tcsr_run(const spmv_tcsr_t *h, const float *d_x, float *d_y, void *stream);
+SPMV_API int spmv_tcsr_run_host(const spmv_tcsr_t *h, const float *x_host, float *y_host, float *kernel_ms);
+SPMV_API int spmv_tcsr_destroy(spmv_tcsr_t *h);
+
 /* ---- synthetic CSR of stated (rows, cols, nnz) ---------------------------
  * Counter-based generator (DESIGN.md "Synthetic workloads"): element k of
  * global row r is a pure function of (seed, r, k, row length, band), so the

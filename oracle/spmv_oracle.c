@@ -86,6 +86,42 @@ ORACLE_API void oracle_csr_fill(int M, int N, const float *A, int32_t *col_idx, 
     }
 }
 
+/* ------------------------------------------------------------------ */
+/* tcsr.cpp:5-38 -- tiled bitmap-CSR.  Blocks of 32 outputs x 32 inputs, */
+/* ordered output strip (block_x) outer, input block (block_y) inner;   */
+/* inside a block bit index i*32+j = (output column i, input row j), so  */
+/* word i of the block belongs to output block_x+i and bit j to input    */
+/* block_y+j; values are appended in that bit order; blk_idx is the      */
+/* exclusive prefix of nonzeros per block with one trailing sentinel.    */
+/* M and N must be multiples of 32 (the reference asserts it,            */
+/* tester.cpp:9-10, and indexes out of range otherwise).                 */
+/* Returns nnz; vals may be NULL for a counting pass.                    */
+/* ------------------------------------------------------------------ */
+ORACLE_API int64_t oracle_tcsr_build(int M, int N, const float *A, int32_t *blk_idx, uint32_t *bitmaps,
+                                     float *vals)
+{
+    int64_t value_index = 0, bit_index = 0, nblk = 0;
+    memset(bitmaps, 0, sizeof(uint32_t) * ((size_t)M * N / 32));
+    blk_idx[nblk++] = 0;
+    for (int bx = 0; bx < N; bx += 32) {
+        for (int by = 0; by < M; by += 32) {
+            for (int i = 0; i < 32; i++) {
+                for (int j = 0; j < 32; j++) {
+                    float v = A[(size_t)(by + j) * N + (bx + i)];
+                    if (v != 0.0f) {
+                        if (vals) vals[value_index] = v;
+                        value_index++;
+                        bitmaps[bit_index / 32] |= 1u << (bit_index % 32);
+                    }
+                    bit_index++;
+                }
+            }
+            blk_idx[nblk++] = (int32_t)value_index;
+        }
+    }
+    return value_index;
+}
+
 /* tester.cpp:36-45 -- y[i] = sum_j x[j] * A[j*N+i], fp32, j ascending. */
 ORACLE_API void oracle_sgemv_dense(int M, int N, const float *A, const float *X, float *Y)
 {

@@ -44,6 +44,13 @@ SIGNATURES = {
     "spmv_csr_run_host": (C.c_int, [_H, C.c_int, _f32p, _f32p, C.POINTER(C.c_float)]),
     "spmv_dense_gemv": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _vp]),
     "spmv_dense_gemv_host": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.POINTER(C.c_float)]),
+    "spmv_tcsr_from_dense_host": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
+    "spmv_tcsr_from_dense_device": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
+    "spmv_tcsr_sizes": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "spmv_tcsr_download": (C.c_int, [_H, _i32p, _i32p, _f32p]),
+    "spmv_tcsr_run": (C.c_int, [_H, _f32p, _f32p, _vp]),
+    "spmv_tcsr_run_host": (C.c_int, [_H, _f32p, _f32p, C.POINTER(C.c_float)]),
+    "spmv_tcsr_destroy": (C.c_int, [_H]),
     "spmv_synth_fill": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                   _i32p, _i32p, _f32p, _vp]),
     "spmv_synth_x": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, _f32p, _vp]),
@@ -196,6 +203,61 @@ class CsrMatrix:
             check(lib().spmv_csr_destroy(self._h))
             self._h = C.c_void_p()
             self._keep = ()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TcsrMatrix:
+    """Owner of one ``spmv_tcsr_t``: the reference's tiled bitmap-CSR (tcsr.cpp:5-38) on the device."""
+
+    def __init__(self, handle: int, M: int, N: int):
+        self._h = C.c_void_p(handle)
+        self.M, self.N = M, N
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().spmv_tcsr_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.n_blk_idx, self.n_bitmaps, self.nnz = a.value, b.value, c.value
+
+    @classmethod
+    def from_dense_host(cls, A):
+        import numpy as np
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        M, N = A.shape
+        h = C.c_void_p()
+        check(lib().spmv_tcsr_from_dense_host(M, N, _ptr(A), 0, C.byref(h)))
+        return cls(h.value, M, N)
+
+    @classmethod
+    def from_dense_device(cls, A):
+        M, N = A.shape
+        h = C.c_void_p()
+        check(lib().spmv_tcsr_from_dense_device(M, N, _ptr(A), _stream_handle(), C.byref(h)))
+        return cls(h.value, M, N)
+
+    def download(self):
+        import numpy as np
+        bi = np.empty(self.n_blk_idx, np.int32)
+        bm = np.empty(self.n_bitmaps, np.uint32)
+        va = np.empty(self.nnz, np.float32)
+        check(lib().spmv_tcsr_download(self._h, _ptr(bi), _ptr(bm), _ptr(va)))
+        return bi, bm, va
+
+    def run(self, x, y, stream=None) -> None:
+        assert x.numel() >= self.M and y.numel() >= self.N
+        check(lib().spmv_tcsr_run(self._h, _ptr(x), _ptr(y), _stream_handle(stream)))
+
+    def run_host(self, x, y) -> float:
+        ms = C.c_float()
+        check(lib().spmv_tcsr_run_host(self._h, _ptr(x), _ptr(y), C.byref(ms)))
+        return ms.value
+
+    def close(self) -> None:
+        if self._h:
+            check(lib().spmv_tcsr_destroy(self._h))
+            self._h = C.c_void_p()
 
     def __del__(self):
         try:

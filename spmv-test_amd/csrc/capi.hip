@@ -350,6 +350,86 @@ int spmv_dense_gemv_host(int M, int N, const float *A_host, const float *x_host,
     return SPMV_OK;
 }
 
+static int tcsr_check_dims(int M, int N, const void *A, const void *out)
+{
+    if (!out || M < 0 || N < 0 || (M % 32) || (N % 32) || (!A && (int64_t)M * N > 0) || (int64_t)M * N >= (1LL << 36)) {
+        set_error("spmv_tcsr_from_dense: M and N must be non-negative multiples of 32 (got %d x %d)", M, N);
+        return SPMV_ERR_INVALID;
+    }
+    return require_device();
+}
+
+int spmv_tcsr_from_dense_device(int M, int N, const float *d_A, void *stream, spmv_tcsr_t **out)
+{
+    int rc = tcsr_check_dims(M, N, d_A, out);
+    if (rc) return rc;
+    return tcsr_from_dense(M, N, d_A, (hipStream_t)stream, out);
+}
+
+int spmv_tcsr_from_dense_host(int M, int N, const float *A_host, void *stream, spmv_tcsr_t **out)
+{
+    int rc = tcsr_check_dims(M, N, A_host, out);
+    if (rc) return rc;
+    DevBuf dA;
+    const size_t bytes = sizeof(float) * (size_t)M * (size_t)N;
+    SPMV_HIP_TRY(dA.alloc(bytes));
+    SPMV_HIP_TRY(hipMemcpyAsync(dA.p, A_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    rc = tcsr_from_dense(M, N, (const float *)dA.p, (hipStream_t)stream, out);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    return rc;
+}
+
+int spmv_tcsr_sizes(const spmv_tcsr_t *h, int64_t *n_blk_idx, int64_t *n_bitmaps, int64_t *n_vals)
+{
+    if (!h) { set_error("spmv_tcsr_sizes: null handle"); return SPMV_ERR_INVALID; }
+    return tcsr_sizes(*h, n_blk_idx, n_bitmaps, n_vals);
+}
+
+int spmv_tcsr_download(const spmv_tcsr_t *h, int32_t *blk_idx, uint32_t *bitmaps, float *vals)
+{
+    if (!h) { set_error("spmv_tcsr_download: null handle"); return SPMV_ERR_INVALID; }
+    return tcsr_download(*h, blk_idx, bitmaps, vals);
+}
+
+int spmv_tcsr_run(const spmv_tcsr_t *h, const float *d_x, float *d_y, void *stream)
+{
+    if (!h || !d_x || !d_y) { set_error("spmv_tcsr_run: null argument"); return SPMV_ERR_INVALID; }
+    return tcsr_run(*h, d_x, d_y, (hipStream_t)stream);
+}
+
+int spmv_tcsr_run_host(const spmv_tcsr_t *h, const float *x_host, float *y_host, float *kernel_ms)
+{
+    if (!h || !x_host || !y_host) { set_error("spmv_tcsr_run_host: null argument"); return SPMV_ERR_INVALID; }
+    int64_t nb = 0, nw = 0, nv = 0;
+    tcsr_sizes(*h, &nb, &nw, &nv);
+    int M = 0, N = 0;
+    tcsr_dims(*h, &M, &N);
+    DevBuf dx, dy;
+    EventPair ev;
+    SPMV_HIP_TRY(dx.alloc(sizeof(float) * (size_t)M));
+    SPMV_HIP_TRY(dy.alloc(sizeof(float) * (size_t)N));
+    SPMV_HIP_TRY(hipMemcpy(dx.p, x_host, sizeof(float) * (size_t)M, hipMemcpyHostToDevice));
+    SPMV_HIP_TRY(hipEventCreate(&ev.a));
+    SPMV_HIP_TRY(hipEventCreate(&ev.b));
+    SPMV_HIP_TRY(hipDeviceSynchronize());
+    SPMV_HIP_TRY(hipEventRecord(ev.a, nullptr));
+    int rc = tcsr_run(*h, (const float *)dx.p, (float *)dy.p, nullptr);
+    SPMV_HIP_TRY(hipEventRecord(ev.b, nullptr));
+    SPMV_HIP_TRY(hipEventSynchronize(ev.b));
+    if (rc) return rc;
+    float ms = 0.0f;
+    SPMV_HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+    if (kernel_ms) *kernel_ms = ms;
+    SPMV_HIP_TRY(hipMemcpy(y_host, dy.p, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost));
+    return SPMV_OK;
+}
+
+int spmv_tcsr_destroy(spmv_tcsr_t *h)
+{
+    tcsr_free(h);
+    return SPMV_OK;
+}
+
 int spmv_dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, void *stream)
 {
     if (M < 0 || N < 0 || ((int64_t)M * N > 0 && (!d_A || !d_x)) || (N > 0 && !d_y)) {

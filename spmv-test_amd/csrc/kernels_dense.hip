@@ -66,6 +66,14 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(int64_t n, int32_t *__r
     if (t == 1023) *total_out = (int32_t)part[1023];
 }
 
+int exclusive_scan_i32(int32_t *d_data, int64_t n, int32_t *d_total, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, n, d_data, d_total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_exclusive_scan", __FILE__, __LINE__);
+    return SPMV_OK;
+}
+
 // row_ptr[i] = offs[i*kSlabs] for i < N, row_ptr[N] = nnz
 __global__ void k_row_ptr_from_offsets(int N, const int32_t *__restrict__ offs, const int32_t *__restrict__ total,
                                        int32_t *__restrict__ row_ptr)

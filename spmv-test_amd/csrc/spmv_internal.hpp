@@ -53,6 +53,8 @@ struct ChunkPlan {
 
 }  // namespace spmv
 
+struct spmv_tcsr;  // kernels_tcsr.hip
+
 // The opaque handle of include/spmv_hip.h.
 struct spmv_csr {
     int64_t rows = 0, cols = 0, nnz = 0;
@@ -82,6 +84,16 @@ void destroy_plans(spmv_csr &h);
 
 int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out);
 int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s);
+
+// in-place exclusive scan of n int32 (one 1024-thread workgroup); the total goes to *d_total
+int exclusive_scan_i32(int32_t *d_data, int64_t n, int32_t *d_total, hipStream_t s);
+
+int tcsr_from_dense(int M, int N, const float *d_A, hipStream_t s, spmv_tcsr_t **out);
+int tcsr_run(const spmv_tcsr &h, const float *d_x, float *d_y, hipStream_t s);
+int tcsr_sizes(const spmv_tcsr &h, int64_t *n_blk_idx, int64_t *n_bitmaps, int64_t *n_vals);
+int tcsr_download(const spmv_tcsr &h, int32_t *blk_idx, uint32_t *bitmaps, float *vals);
+void tcsr_free(spmv_tcsr *h);
+void tcsr_dims(const spmv_tcsr &h, int *M, int *N);
 
 int synth_fill(uint64_t seed, int64_t row0, int64_t n_local, int64_t rows, int64_t cols, int64_t band,
                const int32_t *d_row_ptr, int32_t *d_col_idx, float *d_vals, hipStream_t s);

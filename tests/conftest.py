@@ -51,6 +51,9 @@ class Golden:
         self.y = z["y_dense"]
         # our layout: rows+1 entries with the nnz sentinel (csr_naive.cu:15 substitutes it)
         self.row_ptr = np.concatenate([self.ref_row_ptrs, [len(self.vals)]]).astype(np.int32)
+        self.tcsr = None
+        if "tcsr_blk_idx" in z.files:      # reference TCSRMatrix arrays (32-aligned fixtures only)
+            self.tcsr = (z["tcsr_blk_idx"], z["tcsr_bitmaps"], z["tcsr_vals"])
         if "A" in z.files:
             self.A = z["A"]
         else:

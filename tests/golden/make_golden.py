@@ -44,6 +44,25 @@ def ref_csr(A):
     return rp, ci, va
 
 
+def ref_tcsr(A):
+    """The reference's TCSRMatrix (src/tcsr.cpp:5-38) on A; needs M, N multiples of 32."""
+    lib = ctypes.CDLL(str(ROOT / "oracle" / "_ref" / "libref_formats.so"))
+    lib.ref_tcsr_build.restype = ctypes.c_void_p
+    lib.ref_tcsr_build.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 3
+    lib.ref_tcsr_copy.argtypes = [ctypes.c_void_p] * 4
+    lib.ref_tcsr_free.argtypes = [ctypes.c_void_p]
+    A = np.ascontiguousarray(A, np.float32)
+    M, N = A.shape
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    h = lib.ref_tcsr_build(M, N, A.ctypes.data, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    bi = np.empty(a.value, np.int32)
+    bm = np.empty(b.value, np.uint32)
+    va = np.empty(c.value, np.float32)
+    lib.ref_tcsr_copy(h, bi.ctypes.data, bm.ctypes.data, va.ctypes.data)
+    lib.ref_tcsr_free(h)
+    return bi, bm, va
+
+
 def tester_style(M, N, a_zero, x_zero, seed):
     """Inputs in the style of tester.cpp:103-121,151-167 with a fixed PCG64 seed."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -89,6 +108,10 @@ def main():
         out = dict(M=np.int32(M), N=np.int32(N), x=x, ref_row_ptrs=rp, ref_col_idxs=ci, ref_vals=va,
                    y_dense=y, y_source=np.array("oracle_sgemv_dense restating src/tester.cpp:36-45"),
                    csr_source=np.array("reference CSRMatrix, src/matrix_csr.cpp:5-23, via oracle/_ref"))
+        if M % 32 == 0 and N % 32 == 0:   # the reference's tiled bitmap-CSR of the same matrix
+            bi, bm, tv = ref_tcsr(A)
+            out.update(tcsr_blk_idx=bi, tcsr_bitmaps=bm, tcsr_vals=tv,
+                       tcsr_source=np.array("reference TCSRMatrix, src/tcsr.cpp:5-38, via oracle/_ref"))
         if A.size <= 128 * 128:
             out["A"] = A      # keep the dense matrix where it is small (needed for -0.0f)
         np.savez_compressed(HERE / f"{name}.npz", **out)

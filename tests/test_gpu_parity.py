@@ -207,3 +207,48 @@ def test_launchers_from_python_match_oracle(pkg, oracle, gpu):
         assert oracle.L.oracle_compare(448, y_ref.ctypes.data, y.ctypes.data, ctypes.c_float(1e-3)) == 0  # tester.cpp:75
         if "awsp_ref" in sym or "csr_naive" in sym or "naive_gemv" in sym:
             assert np.array_equal(y.view(np.uint32), y_ref.view(np.uint32)), sym
+
+
+# ---- the reference's tiled bitmap-CSR (f-3) -------------------------------------------------------
+def test_tcsr_device_builder_is_bit_exact(pkg, gpu, golden):
+    """spmv_tcsr_from_dense_host vs the reference's TCSRMatrix arrays (tcsr.cpp:5-38)."""
+    if golden.tcsr is None:
+        with pytest.raises(pkg.capi.SpmvError) as e:       # not 32-aligned: refused, like the reference's assert
+            pkg.capi.TcsrMatrix.from_dense_host(golden.A)
+        assert e.value.status == pkg.capi.ERR_INVALID
+        return
+    t = pkg.capi.TcsrMatrix.from_dense_host(golden.A)
+    bi, bm, va = t.download()
+    rbi, rbm, rva = golden.tcsr
+    assert np.array_equal(bi, rbi)
+    assert np.array_equal(bm, rbm)
+    assert np.array_equal(va.view(np.uint32), rva.view(np.uint32))
+
+
+def test_tcsr_spmv_matches_oracle(pkg, oracle, gpu, golden):
+    if golden.tcsr is None:
+        pytest.skip("not 32-aligned")
+    t = pkg.capi.TcsrMatrix.from_dense_host(golden.A)
+    y = np.full(golden.N, np.nan, np.float32)
+    ms = t.run_host(golden.x, y)
+    assert ms > 0
+    y64, mag = oracle.spmv_f64(golden.row_ptr, golden.col_idx, golden.vals, golden.x)
+    assert_close_to_oracle(y, y64, mag, f"tcsr/{golden.name}")
+
+
+@pytest.mark.parametrize("M,N,zero", [(4096, 4096, 0.5), (32, 32, 0.0), (2048, 96, 0.9), (64, 4096, 0.97), (320, 1024, 1.0)])
+def test_tcsr_tester_regime_and_shapes(pkg, oracle, gpu, M, N, zero):
+    """4096^2 at 50 % is the reference tester's own problem (test/main.cpp:4, tester.cpp:106)."""
+    import torch
+    A, x = pkg.workloads.dense_random(M, N, zero, seed=M + N)
+    t = pkg.capi.TcsrMatrix.from_dense_device(torch.from_numpy(A).to(gpu))
+    bi, bm, va = t.download()
+    obi, obm, ova = oracle.tcsr_from_dense(A)
+    assert np.array_equal(bi, obi) and np.array_equal(bm, obm) and np.array_equal(va.view(np.uint32), ova.view(np.uint32))
+    dx = torch.from_numpy(x).to(gpu)
+    dy = torch.full((N,), float("nan"), device=gpu)
+    t.run(dx, dy)
+    torch.cuda.synchronize()
+    rp, ci, cv = oracle.csr_from_dense(A)
+    y64, mag = oracle.spmv_f64(rp, ci, cv, x)
+    assert_close_to_oracle(dy.cpu().numpy(), y64, mag, f"tcsr {M}x{N}")

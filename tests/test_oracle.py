@@ -89,3 +89,16 @@ def test_csr_builder_matches_live_reference(oracle, shape, zero):
     orp, oci, ova = oracle.csr_from_dense(A)
     assert a.value == N and np.array_equal(orp[:-1], rp) and orp[-1] == c.value
     assert np.array_equal(oci, ci) and np.array_equal(ova.view(np.uint32), va.view(np.uint32))
+
+
+def test_tcsr_builder_matches_reference_fixture(oracle, golden):
+    """tcsr.cpp:5-38 -- blk_idx, bitmaps and values bit for bit (32-aligned fixtures)."""
+    if golden.tcsr is None:
+        pytest.skip("fixture is not 32-aligned: the reference's TCSR is undefined for it")
+    bi, bm, va = oracle.tcsr_from_dense(golden.A)
+    rbi, rbm, rva = golden.tcsr
+    assert len(rbi) == (golden.M // 32) * (golden.N // 32) + 1
+    assert np.array_equal(bi, rbi) and np.array_equal(bm, rbm)
+    assert np.array_equal(va.view(np.uint32), rva.view(np.uint32))
+    # the same nonzeros as the CSR of the same matrix, in a different order
+    assert len(va) == len(golden.vals) and np.array_equal(np.sort(va), np.sort(golden.vals))
