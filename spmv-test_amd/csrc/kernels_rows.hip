@@ -1,6 +1,6 @@
 // kernels_rows.hip -- row-mapped CSR SpMV kernels for gfx950 (wave64).
 //
-//   k_scalar   thread per row, sequential, unfused mul+add
+//   k_scalar   thread per row, sequential, unfused mul+add (operands staged by the workgroup)
 //              role of csr_naive_kernel (/root/reference/src/kernels/csr_naive.cu:6-23);
 //              the same per-row operation order as SgemvCPU (src/tester.cpp:36-45),
 //              so results are bit-identical to the CPU oracle.
@@ -16,6 +16,16 @@
 namespace spmv {
 
 // ---------------------------------------------------------------------------
+// k_scalar: ONE THREAD PER ROW, terms added in ascending k with an unfused multiply and add --
+// exactly the arithmetic of the host loop, so y is bit-identical to SgemvCPU / the CSR walk.
+// What is re-derived is only how the operands reach the thread: the 256 rows of a workgroup own one
+// contiguous range of nonzeros, so when that range fits the LDS buffer the workgroup streams it
+// with coalesced loads (lane-consecutive nonzeros), rounds each product x*val once, parks the
+// products in LDS, and every thread then adds ITS row's products in order.  A naive thread-per-row
+// loop reads col_idx/vals at a stride of one row per lane (4-byte loads, 64 cache lines per wave
+// instruction); a workgroup whose rows hold more than kScalarCap nonzeros falls back to that loop.
+constexpr int kScalarCap = 8192;  // products staged per workgroup (32 KiB of LDS -> 5 workgroups per CU)
+
 __global__ __launch_bounds__(kBlock) void k_scalar(int64_t rows, const int32_t *__restrict__ row_ptr,
                                                    const int32_t *__restrict__ col_idx,
                                                    const float *__restrict__ vals,
@@ -24,15 +34,31 @@ __global__ __launch_bounds__(kBlock) void k_scalar(int64_t rows, const int32_t *
     // two roundings per term, like the host loop: HIP's __fmul_rn/__fadd_rn are plain operators
     // that hipcc would contract into v_fma_f32 under its default -ffp-contract=fast
 #pragma clang fp contract(off)
-    int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r >= rows) return;
-    int32_t b = row_ptr[r], e = row_ptr[r + 1];
-    float acc = 0.0f;
-    for (int32_t k = b; k < e; ++k) {
-        float p = x[col_idx[k]] * vals[k];
-        acc = acc + p;
+    __shared__ float prod[kScalarCap];
+    const int64_t r0 = (int64_t)blockIdx.x * kBlock;
+    const int64_t r = r0 + threadIdx.x;
+    const int64_t rend = (r0 + kBlock < rows) ? r0 + kBlock : rows;
+    const int32_t wb = row_ptr[r0], we = row_ptr[rend];  // the workgroup's nonzero range
+    const int32_t b = r < rows ? row_ptr[r] : 0, e = r < rows ? row_ptr[r + 1] : 0;
+    if (we - wb <= kScalarCap) {
+        for (int32_t k = wb + (int32_t)threadIdx.x; k < we; k += kBlock) {
+            const float p = x[col_idx[k]] * vals[k];
+            prod[k - wb] = p;
+        }
+        __syncthreads();
+        if (r < rows) {
+            float acc = 0.0f;
+            for (int32_t k = b; k < e; ++k) acc = acc + prod[k - wb];
+            y[r] = acc;
+        }
+    } else if (r < rows) {
+        float acc = 0.0f;
+        for (int32_t k = b; k < e; ++k) {
+            const float p = x[col_idx[k]] * vals[k];
+            acc = acc + p;
+        }
+        y[r] = acc;
     }
-    y[r] = acc;
 }
 
 // ---------------------------------------------------------------------------
