@@ -24,7 +24,7 @@
 //   * TILED stages the chunk's column window of x in LDS and gathers from LDS instead of L1/L2
 //     (a 4-byte gather that misses L1 costs a whole L2 request and a 128-byte line).  The window
 //     lives in the SAME LDS region the products are written to afterwards, so it costs no
-//     occupancy.  The region grows with the workgroup: 256/512/1024 threads hold 4608/9216/18432
+//     occupancy.  The region grows with the workgroup: 256/512/1024 threads hold 4832/9664/19328
 //     floats at the same LDS bytes per wave; the plan picks the smallest workgroup whose region
 //     covers the windows of >= 90 % of the chunks, and a chunk whose window does not fit
 //     gathers from global memory.
@@ -37,20 +37,27 @@ namespace spmv {
 using i4 = int __attribute__((ext_vector_type(4)));
 using f4 = float __attribute__((ext_vector_type(4)));
 
-constexpr int kGroup = 16;  // lanes that share one long segment
+#ifndef SPMV_T_GROUP
+#define SPMV_T_GROUP 16
+#endif
+constexpr int kGroup = SPMV_T_GROUP;  // lanes that share one long segment
 
 __host__ __device__ constexpr int chunk_of(int block) { return block * kNnzPerThread; }
 __host__ __device__ constexpr int prod_words(int block) { return chunk_of(block) + (chunk_of(block) >> 5); }
-// LDS region per workgroup: the padded product buffer (16.5 B/thread... 4224 floats per 256
-// threads) rounded up to what still lets 2048 threads share a CU's 160 KiB next to the
-// long-segment queue: 18 KiB per 256 threads = 4608 / 9216 / 18432 floats.
-__host__ __device__ constexpr int region_words(int block) { return block * 18; }
+// LDS region per workgroup: the padded product buffer (4224 floats per 256 threads) rounded up to
+// what still lets 2048 threads share a CU's 160 KiB next to the segment queues (1.1 KiB per 256
+// threads): 4832 / 9664 / 19328 floats.
+__host__ __device__ constexpr int region_words(int block) { return (block / 256) * 4832; }
 static_assert(region_words(256) >= prod_words(256), "region must hold the products");
 __host__ __device__ constexpr int max_long(int block) { return chunk_of(block) / (kShortSeg + 1) + 2; }
 constexpr int kHugeSeg = 512;  // segments longer than this are summed by the whole workgroup
 __host__ __device__ constexpr int max_huge(int block) { return chunk_of(block) / (kHugeSeg + 1) + 2; }
 
+#ifdef SPMV_T_NOPAD
+__device__ __forceinline__ int pad_idx(int i) { return i; }
+#else
 __device__ __forceinline__ int pad_idx(int i) { return i + (i >> 5); }
+#endif
 
 // chunk handled by this block: XCD j = blockIdx % 8 gets a contiguous range
 __device__ __forceinline__ int xcd_chunk(int bid, int n)
@@ -250,7 +257,10 @@ __device__ __forceinline__ Walk first_chunk(bool persist, int bid, int grid, int
 // second launch-bounds argument keeps the kernel at <= 64 VGPRs (8 waves/SIMD).  Persistent: the
 // next chunk's 32 stream registers stay live through the reduction, so it is built for 80 VGPRs
 // (6 waves/SIMD; 4 for the 1024-thread workgroup, of which only one fits a CU then).
-__host__ __device__ constexpr int waves_per_simd(int block, bool persist) { return !persist ? 8 : (block == 1024 ? 4 : 6); }
+#ifndef SPMV_T_WAVES
+#define SPMV_T_WAVES 8
+#endif
+__host__ __device__ constexpr int waves_per_simd(int block, bool persist) { return !persist ? SPMV_T_WAVES : (block == 1024 ? 4 : 6); }
 
 template <int BLOCK, bool TILED, bool PERSIST>
 __global__ __launch_bounds__(BLOCK, waves_per_simd(BLOCK, PERSIST))

@@ -36,8 +36,15 @@ constexpr int kXcds = 8;           // MI355X: 8 XCDs, blocks dealt round-robin o
 
 // ADAPTIVE / TILED chunking: every lane streams kNnzPerThread consecutive-by-4 nonzeros
 // (col_idx + vals = 8 B each) with 16-byte loads; a workgroup of B threads owns B*16 nonzeros.
-constexpr int kNnzPerThread = 16;
-constexpr int kShortSeg = 16;                      // row segments up to this long: one lane sums them
+// (the SPMV_T_* macros exist for A/B builds, tools/explore.py; the shipped values are the defaults)
+#ifndef SPMV_T_NPT
+#define SPMV_T_NPT 16
+#endif
+#ifndef SPMV_T_SHORT
+#define SPMV_T_SHORT 32
+#endif
+constexpr int kNnzPerThread = SPMV_T_NPT;
+constexpr int kShortSeg = SPMV_T_SHORT;            // row segments up to this long: one lane sums them
 
 // Chunk boundaries (and, for TILED, column windows) for workgroups of `block` threads.
 struct ChunkPlan {
