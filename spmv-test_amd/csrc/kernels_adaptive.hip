@@ -50,7 +50,10 @@ __host__ __device__ constexpr int prod_words(int block) { return chunk_of(block)
 __host__ __device__ constexpr int region_words(int block) { return (block / 256) * 4832; }
 static_assert(region_words(256) >= prod_words(256), "region must hold the products");
 __host__ __device__ constexpr int max_long(int block) { return chunk_of(block) / (kShortSeg + 1) + 2; }
-constexpr int kHugeSeg = 512;  // segments longer than this are summed by the whole workgroup
+#ifndef SPMV_T_HUGE
+#define SPMV_T_HUGE 512
+#endif
+constexpr int kHugeSeg = SPMV_T_HUGE;  // segments longer than this are summed by the whole workgroup
 __host__ __device__ constexpr int max_huge(int block) { return chunk_of(block) / (kHugeSeg + 1) + 2; }
 
 #ifdef SPMV_T_NOPAD
@@ -494,11 +497,12 @@ static void free_plan(ChunkPlan &p)
     p = ChunkPlan();
 }
 
-static int max_passes(int block) { return block == 1024 ? 12 : (block == 512 ? 4 : 2); }
+static int default_passes(int block) { return block == 1024 ? 12 : (block == 512 ? 4 : 2); }
 
-// chunk boundaries (+ column windows when `windows`) for workgroups of `block` threads
-static int build_plan(const spmv_csr &h, int block, bool windows, hipStream_t s, ChunkPlan &p, int *single, int *full)
+// chunk boundaries (+ column windows when `maxpass` > 0) for workgroups of `block` threads
+static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, ChunkPlan &p, int *single, int *full)
 {
+    const bool windows = maxpass > 0;
     free_plan(p);
     p.block = block;
     // tuning knob SPMV_PERSIST=0|1, read when the plan is made (default 0: the persistent form
@@ -521,7 +525,7 @@ static int build_plan(const spmv_csr &h, int block, bool windows, hipStream_t s,
         int32_t *d_stats = p.d_win + 2 * (size_t)p.nchunks;
         SPMV_HIP_TRY(hipMemsetAsync(d_stats, 0, 2 * sizeof(int32_t), s));
         hipLaunchKernelGGL(k_plan_windows, dim3(p.nchunks), dim3(256), 0, s, h.nnz, h.cols, p.nchunks, chunk,
-                           h.d_col_idx, p.d_win, d_stats, region_words(block), max_passes(block));
+                           h.d_col_idx, p.d_win, d_stats, region_words(block), maxpass);
         if ((rc = check_launch("k_plan_windows"))) return rc;
         int32_t stats[2] = {0, 0};
         SPMV_HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, s));
@@ -534,33 +538,87 @@ static int build_plan(const spmv_csr &h, int block, bool windows, hipStream_t s,
     return SPMV_OK;
 }
 
+int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s);
+
 int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
 {
     if (!tiled) {
         if (h.plan_adaptive.block) return SPMV_OK;
-        return build_plan(h, 256, false, s, h.plan_adaptive, nullptr, nullptr);
+        return build_plan(h, 256, 0, s, h.plan_adaptive, nullptr, nullptr);
     }
     if (h.plan_tiled.block) return SPMV_OK;
-    // Workgroup size: the smallest whose LDS region holds the whole column span of >= 90 % of the
-    // chunks in ONE pass (same LDS bytes and waves per CU for all three, but a larger workgroup
-    // pays more per barrier).  Failing that, 1024 threads with multi-pass staging when that
-    // covers at least half of the chunks; otherwise the matrix has no usable column locality and
-    // 256-thread workgroups gather from global memory (staging only what is worth it).
-    int forced = 0;
-    if (const char *e = getenv("SPMV_TILED_BLOCK")) forced = atoi(e);  // tuning knob: 256 | 512 | 1024
+
+    // tuning knobs: SPMV_TILED_BLOCK = 256|512|1024 and SPMV_MAXPASS = 1..64 pin the geometry
+    int forced = 0, forced_pass = 0;
+    if (const char *e = getenv("SPMV_TILED_BLOCK")) forced = atoi(e);
     if (forced != 256 && forced != 512 && forced != 1024) forced = 0;
-    if (forced) return build_plan(h, forced, true, s, h.plan_tiled, nullptr, nullptr);
-    const int cands[3] = {256, 512, 1024};
-    int full1024 = 0;
-    for (int k = 0; k < 3; ++k) {
-        int single = 0, full = 0;
-        int rc = build_plan(h, cands[k], true, s, h.plan_tiled, &single, &full);
-        if (rc) return rc;
-        if (h.plan_tiled.nchunks == 0 || single >= 0.9 * h.plan_tiled.nchunks) return SPMV_OK;
-        full1024 = full;
+    if (const char *e = getenv("SPMV_MAXPASS")) forced_pass = atoi(e);
+    if (forced_pass < 1 || forced_pass > 64) forced_pass = 0;
+    if (forced) return build_plan(h, forced, forced_pass ? forced_pass : default_passes(forced), s, h.plan_tiled, nullptr, nullptr);
+
+    bool autotune = h.nnz >= (1 << 20);  // below ~1M nonzeros a launch is a few microseconds either way
+    if (const char *e = getenv("SPMV_AUTOTUNE")) autotune = atoi(e) != 0;
+    if (!autotune) {
+        // Heuristic: the smallest workgroup whose LDS region holds the whole column span of >= 90 %
+        // of the chunks in ONE pass (same LDS bytes and waves per CU for all three, but a larger
+        // workgroup pays more per barrier); failing that, 1024 threads with multi-pass staging when
+        // that covers at least half of the chunks; otherwise 256 threads (global gathers).
+        const int cands[3] = {256, 512, 1024};
+        int full1024 = 0;
+        for (int k = 0; k < 3; ++k) {
+            int single = 0, full = 0;
+            int rc = build_plan(h, cands[k], default_passes(cands[k]), s, h.plan_tiled, &single, &full);
+            if (rc) return rc;
+            if (h.plan_tiled.nchunks == 0 || single >= 0.9 * h.plan_tiled.nchunks) return SPMV_OK;
+            full1024 = full;
+        }
+        if (full1024 >= 0.5 * h.plan_tiled.nchunks) return SPMV_OK;
+        return build_plan(h, 256, default_passes(256), s, h.plan_tiled, nullptr, nullptr);
     }
-    if (full1024 >= 0.5 * h.plan_tiled.nchunks) return SPMV_OK;  // keep the 1024-thread multi-pass plan
-    return build_plan(h, 256, true, s, h.plan_tiled, nullptr, nullptr);
+
+    // Autotune (the default for real sizes): the best (workgroup size, pass budget) depends on how the
+    // column spans are distributed -- a band, a band plus a few long rows, power-law rows -- so the
+    // plan times the kernel itself on the candidates and keeps the fastest.  Costs a few launches,
+    // once per matrix (the reference pays a host-side format build per launcher call).
+    struct Cand { int block, maxpass; };
+    const Cand cands[] = {{256, 2}, {512, 4}, {512, 8}, {1024, 6}, {1024, 12}};
+    DevPtr<float> xt, yt;
+    SPMV_HIP_TRY(xt.alloc((size_t)h.cols));
+    SPMV_HIP_TRY(yt.alloc((size_t)h.rows));
+    SPMV_HIP_TRY(hipMemsetAsync(xt.p, 0, sizeof(float) * (size_t)(h.cols ? h.cols : 1), s));
+    hipEvent_t e0, e1;
+    SPMV_HIP_TRY(hipEventCreate(&e0));
+    SPMV_HIP_TRY(hipEventCreate(&e1));
+    ChunkPlan best;
+    float best_ms = 0.0f;
+    int rc = SPMV_OK;
+    for (const Cand &c : cands) {
+        ChunkPlan &p = h.plan_tiled;
+        int single = 0, full = 0;
+        if ((rc = build_plan(h, c.block, c.maxpass, s, p, &single, &full))) break;
+        if (p.nchunks == 0) { best = p; p = ChunkPlan(); break; }
+        if ((rc = launch_adaptive(h, xt.p, yt.p, true, s))) break;  // warm (code object, attribute)
+        hipEventRecord(e0, s);
+        for (int i = 0; i < 3 && rc == SPMV_OK; ++i) rc = launch_adaptive(h, xt.p, yt.p, true, s);
+        hipEventRecord(e1, s);
+        if (rc || hipEventSynchronize(e1) != hipSuccess) { rc = rc ? rc : SPMV_ERR_HIP; break; }
+        float ms = 0.0f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (!best.block || ms < best_ms) {
+            free_plan(best);
+            best = p;
+            best_ms = ms;
+            p = ChunkPlan();  // ownership moved to `best`
+        }
+        // every chunk already staged in one pass: larger workgroups only add barrier cost
+        if (single == best.nchunks && best.block == c.block) break;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    free_plan(h.plan_tiled);
+    if (rc) { free_plan(best); return rc; }
+    h.plan_tiled = best;
+    return SPMV_OK;
 }
 
 void destroy_plans(spmv_csr &h)
