@@ -263,7 +263,14 @@ __device__ __forceinline__ Walk first_chunk(bool persist, int bid, int grid, int
 #ifndef SPMV_T_WAVES
 #define SPMV_T_WAVES 8
 #endif
-__host__ __device__ constexpr int waves_per_simd(int block, bool persist) { return !persist ? SPMV_T_WAVES : (block == 1024 ? 4 : 6); }
+#ifdef SPMV_T_NOPREFETCH
+__host__ __device__ constexpr int waves_per_simd(int block, bool persist) { return SPMV_T_WAVES; }
+#else
+#ifndef SPMV_T_PWAVES
+#define SPMV_T_PWAVES 6
+#endif
+__host__ __device__ constexpr int waves_per_simd(int block, bool persist) { return !persist ? SPMV_T_WAVES : (block == 1024 ? 4 : SPMV_T_PWAVES); }
+#endif
 
 template <int BLOCK, bool TILED, bool PERSIST>
 __global__ __launch_bounds__(BLOCK, waves_per_simd(BLOCK, PERSIST))
@@ -287,7 +294,7 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
     __shared__ float wave_part[BLOCK / kWave];
     __shared__ int long_count, huge_count;
 
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     Walk wk = first_chunk(PERSIST, blockIdx.x, gridDim.x, nrun);
     if (wk.c >= wk.end) return;
     wk.c += chunk0;
@@ -298,10 +305,14 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
     {
         const int64_t b0 = (int64_t)wk.c * kChunkT;
         const int n0 = (int)((nnz - b0) < kChunkT ? (nnz - b0) : kChunkT);
-        load_stream<BLOCK, PERSIST>(b0, n0, TILED ? win[2 * wk.c] : 0, col_idx, vals, tid, cc, vv);
+        load_stream<BLOCK, PERSIST>(b0, n0, TILED ? win[2 * wk.c] : 0, col_idx, vals, tid0, cc, vv);
     }
 
     for (;;) {
+        // (persistent form) keep lane-derived address math inside the iteration: hoisted out of the
+        // loop it costs ~28 VGPRs and spills
+        int tid = tid0;
+        if (PERSIST) asm volatile("" : "+v"(tid));
         const int c = wk.c;
         const int64_t base = (int64_t)c * kChunkT;
         const int n = (int)((nnz - base) < kChunkT ? (nnz - base) : kChunkT);
@@ -386,11 +397,13 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
         // ---- the next chunk's stream, into the registers the products just left
         const int cn = c + wk.stride;
         const bool more = PERSIST && cn < wk.end;
+#ifndef SPMV_T_NOPREFETCH
         if (more) {
             const int64_t bn = (int64_t)cn * kChunkT;
             const int nn = (int)((nnz - bn) < kChunkT ? (nnz - bn) : kChunkT);
             load_stream<BLOCK, PERSIST>(bn, nn, TILED ? win[2 * cn] : 0, col_idx, vals, tid, cc, vv);
         }
+#endif
         __syncthreads();
 
         // ---- short segments: one lane each, sequential (the oracle's order); longer ones are
@@ -461,6 +474,12 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
         if (!more) break;
         __syncthreads();  // the region and the queues are reused by the next chunk
         wk.c = cn;
+#ifdef SPMV_T_NOPREFETCH
+        {
+            const int64_t bn = (int64_t)cn * kChunkT;
+            load_stream<BLOCK, PERSIST>(bn, kChunkT, TILED ? win[2 * cn] : 0, col_idx, vals, tid, cc, vv);
+        }
+#endif
     }
 }
 
