@@ -152,9 +152,15 @@ __global__ __launch_bounds__(BLK, 8) void k_win(const int* __restrict__ col, con
     if (MODE == 0) {
         for (int i = tid * 4; i < wlen; i += BLK * 4) *reinterpret_cast<f4*>(smem + i) = *reinterpret_cast<const f4*>(x + w0 + i);
     } else if (MODE == 2) {
-        for (int i = tid * 4; i < wlen; i += BLK * 4)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(x + w0 + i),
-                                             (void __attribute__((address_space(3)))*)(smem + (i - tid * 4)), 16, 0, 0);
+        // LDS-DMA: the LDS destination is wave-uniform base + lane*16, so the base is the first
+        // float of this WAVE's 1-KiB piece of the pass
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int i0 = 0; i0 < wlen; i0 += BLK * 4) {
+            const int piece = i0 + wave * 256;      // floats
+            if (piece + lane * 4 < wlen)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(x + w0 + piece + lane * 4),
+                                                 (void __attribute__((address_space(3)))*)(smem + piece), 16, 0, 0);
+        }
     }
     __syncthreads();
     f4 xv[V];
