@@ -134,6 +134,9 @@ def main():
 
         def multiply_only():
             A.run(variant, d_x, d_y)
+
+        def finish():
+            pass
     else:
         def bind(h):
             return lambda x, y: h.run(variant, x, y)
@@ -143,6 +146,7 @@ def main():
         sh.broadcast_x(0)                    # the one-off distribution of the dense vector
         d_x = sh.x
         step = sh.step
+        finish = sh.finish
 
         def multiply_only():
             for s_, h in enumerate(handles):
@@ -163,11 +167,13 @@ def main():
     # ---- warm-up, then EXACTLY K timed steps between barrier + synchronize ------------------------
     for _ in range(args.warmup):
         step()
+    finish()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
         step()
+    finish()                                  # every all-gather of the K steps has landed
     ev1.record()
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0

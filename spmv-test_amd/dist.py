@@ -148,9 +148,11 @@ class PipelinedSpmv:
         return dist.all_gather_into_tensor(grp, src, group=self.group, async_op=True)
 
     def step(self) -> torch.Tensor:
-        """One y = A x: S products, S overlapped all-gathers; returns after everything is ENQUEUED
-        with the current stream ordered behind the last gather (so the next step, or a reader of
-        y_full on this stream, sees the complete vector)."""
+        """One y = A x: S products, S overlapped all-gathers.  Everything is ENQUEUED when this returns.
+        Steps pipeline across the call boundary: the product of block s only waits for the previous
+        step's gather of group s (which reads the slot it is about to overwrite), so the tail gathers
+        of one step overlap the head products of the next.  Call ``finish()`` before reading
+        ``y_full`` on the current stream (or at the end of a timed region)."""
         if not self.cuda:
             for s in range(self.S):
                 a, b = self.block_rows(s)
@@ -160,19 +162,28 @@ class PipelinedSpmv:
                     w.wait()
             return self.y_full
         compute = torch.cuda.current_stream(self.device)
-        works = []
+        if not self._pending:
+            self._pending = [None] * self.S
         for s in range(self.S):
             a, b = self.block_rows(s)
+            if self._pending[s] is not None:
+                compute.wait_event(self._pending[s])         # last step's gather of this slot is done
             self.local_spmvs[s](self.x, self.y_full[a:b])
             if self.world > 1:
                 ev = torch.cuda.Event()
                 ev.record(compute)
                 with torch.cuda.stream(self.comm_stream):
                     self.comm_stream.wait_event(ev)          # gather s starts when product s is done
-                    works.append(self._gather_group(s))
-        for w in works:
-            if w is not None:
-                w.wait()                                     # orders the CURRENT stream behind the collective
-        if self.world > 1:
-            compute.wait_stream(self.comm_stream)
+                    w = self._gather_group(s)
+                    if w is not None:
+                        w.wait()                             # orders comm_stream behind the collective
+                    done = torch.cuda.Event()
+                    done.record(self.comm_stream)
+                self._pending[s] = done
+        return self.y_full
+
+    def finish(self) -> torch.Tensor:
+        """Order the current stream behind every outstanding gather; y_full is then complete."""
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         return self.y_full

@@ -99,7 +99,8 @@ def _worker_pipe(rank, world, port, S, q):
         if rank == 0:
             sh.x.copy_(torch.from_numpy(orc.synth_x(w.seed, 0, w.cols)))
         sh.broadcast_x(0)
-        y = sh.step().numpy().copy()
+        sh.step()
+        y = sh.finish().numpy().copy()
         rp_all = W.row_ptr(w)
         ci_all, va_all = orc.synth_fill(w.seed, 0, w.rows, w.rows, w.cols, w.band, rp_all)
         y_ref = orc.spmv(rp_all, ci_all, va_all, orc.synth_x(w.seed, 0, w.cols))

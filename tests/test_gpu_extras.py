@@ -83,8 +83,9 @@ def _rank(rank, world, port, S, q):
         if rank == 0:
             capi.synth_x(w.seed, 0, w.cols, sh.x)
         sh.broadcast_x(0)
-        for _ in range(2):
-            y = sh.step()
+        for _ in range(3):
+            sh.step()
+        y = sh.finish()
         torch.cuda.synchronize()
         y = y.cpu().numpy()
         rp_all = W.row_ptr(w)
