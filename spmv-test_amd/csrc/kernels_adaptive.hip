@@ -56,11 +56,7 @@ __host__ __device__ constexpr int max_long(int block) { return chunk_of(block) /
 constexpr int kHugeSeg = SPMV_T_HUGE;  // segments longer than this are summed by the whole workgroup
 __host__ __device__ constexpr int max_huge(int block) { return chunk_of(block) / (kHugeSeg + 1) + 2; }
 
-#ifdef SPMV_T_NOPAD
-__device__ __forceinline__ int pad_idx(int i) { return i; }
-#else
 __device__ __forceinline__ int pad_idx(int i) { return i + (i >> 5); }
-#endif
 
 // chunk handled by this block: XCD j = blockIdx % 8 gets a contiguous range
 __device__ __forceinline__ int xcd_chunk(int bid, int n)
@@ -260,17 +256,7 @@ __device__ __forceinline__ Walk first_chunk(bool persist, int bid, int grid, int
 // second launch-bounds argument keeps the kernel at <= 64 VGPRs (8 waves/SIMD).  Persistent: the
 // next chunk's 32 stream registers stay live through the reduction, so it is built for 80 VGPRs
 // (6 waves/SIMD; 4 for the 1024-thread workgroup, of which only one fits a CU then).
-#ifndef SPMV_T_WAVES
-#define SPMV_T_WAVES 8
-#endif
-#ifdef SPMV_T_NOPREFETCH
-__host__ __device__ constexpr int waves_per_simd(int block, bool persist) { return SPMV_T_WAVES; }
-#else
-#ifndef SPMV_T_PWAVES
-#define SPMV_T_PWAVES 6
-#endif
-__host__ __device__ constexpr int waves_per_simd(int block, bool persist) { return !persist ? SPMV_T_WAVES : (block == 1024 ? 4 : SPMV_T_PWAVES); }
-#endif
+__host__ __device__ constexpr int waves_per_simd(int block, bool persist) { return !persist ? 8 : (block == 1024 ? 4 : 6); }
 
 template <int BLOCK, bool TILED, bool PERSIST>
 __global__ __launch_bounds__(BLOCK, waves_per_simd(BLOCK, PERSIST))
@@ -397,13 +383,11 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
         // ---- the next chunk's stream, into the registers the products just left
         const int cn = c + wk.stride;
         const bool more = PERSIST && cn < wk.end;
-#ifndef SPMV_T_NOPREFETCH
         if (more) {
             const int64_t bn = (int64_t)cn * kChunkT;
             const int nn = (int)((nnz - bn) < kChunkT ? (nnz - bn) : kChunkT);
             load_stream<BLOCK, PERSIST>(bn, nn, TILED ? win[2 * cn] : 0, col_idx, vals, tid, cc, vv);
         }
-#endif
         __syncthreads();
 
         // ---- short segments: one lane each, sequential (the oracle's order); longer ones are
@@ -474,12 +458,6 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
         if (!more) break;
         __syncthreads();  // the region and the queues are reused by the next chunk
         wk.c = cn;
-#ifdef SPMV_T_NOPREFETCH
-        {
-            const int64_t bn = (int64_t)cn * kChunkT;
-            load_stream<BLOCK, PERSIST>(bn, kChunkT, TILED ? win[2 * cn] : 0, col_idx, vals, tid, cc, vv);
-        }
-#endif
     }
 }
 

@@ -112,3 +112,19 @@ def test_two_ranks_share_the_gpu_and_exchange_y(built, gpu):
         p.join(timeout=300)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=10) for _ in range(2)) == [(0, True), (1, True)]
+
+
+def test_persistent_launch_knob_gives_the_same_answer(pkg, oracle, gpu, monkeypatch):
+    """SPMV_PERSIST=1 (read when the plan is made) walks the chunks with resident workgroups and a
+    software-pipelined stream; measured slower but it must stay correct."""
+    w = pkg.workloads.Workload("t", 8 * pkg.workloads.BLOCK_ROWS, 8 * pkg.workloads.BLOCK_ROWS, "mixed", 16, band=4096)
+    monkeypatch.setenv("SPMV_PERSIST", "1")
+    monkeypatch.setenv("SPMV_AUTOTUNE", "0")
+    prob = synth_problem(pkg, oracle, gpu, w)
+    y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+    for name in ("adaptive", "tiled"):
+        assert_close_to_oracle(prob.run(pkg.capi.VARIANTS[name]), y64, mag, f"persist/{name}")
+    for blk in ("512", "1024"):
+        monkeypatch.setenv("SPMV_TILED_BLOCK", blk)
+        p2 = synth_problem(pkg, oracle, gpu, w)
+        assert_close_to_oracle(p2.run(pkg.capi.TILED), y64, mag, f"persist/tiled/{blk}")
