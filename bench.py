@@ -233,6 +233,7 @@ def main():
                          "kernel_ms": round(kernel_ms, 5), "timing": "HIP events on the launch stream"},
             "step_ms_events": round(step_ms_events, 5), "multiply_only_ms": round(kernel_ms, 5),
             "plan_ms": round(plan_ms, 4), "plan_bytes": sum(h.plan_bytes(variant) for h in handles),
+            "plan": handles[0].plan_describe(variant),
             "setup_s": round(setup_s, 2),
         }
 

@@ -111,8 +111,15 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
 SPMV_API int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream);
 SPMV_API int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void *stream);
 
-/* Bytes of plan metadata the variant reads per run (not credited as algorithmic bytes). */
+/* Bytes of plan data the variant reads per run.  Chunk boundaries, carries and windows come on top
+ * of the CSR arrays; the 16-bit column offsets of SPMV_TILED REPLACE the 4-byte col_idx reads of the
+ * chunks that have them (2 bytes per nonzero instead of 4), so a tiled run can move fewer HBM
+ * bytes than the CSR-algorithmic count. */
 SPMV_API int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant);
+
+/* One-line description of the plan ("block=512 maxpass=4 chunks=32768 single=31080 col16=31080 ...")
+ * written to buf (NUL-terminated, truncated to n). */
+SPMV_API int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n);
 
 /* Run `iters` back-to-back launches on `stream` between two HIP events
  * recorded on that same stream; returns the mean milliseconds per launch.

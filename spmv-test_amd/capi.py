@@ -40,6 +40,7 @@ SIGNATURES = {
     "spmv_csr_plan": (C.c_int, [_H, C.c_int, _vp]),
     "spmv_csr_run": (C.c_int, [_H, C.c_int, _f32p, _f32p, _vp]),
     "spmv_csr_plan_bytes": (C.c_int64, [_H, C.c_int]),
+    "spmv_csr_plan_describe": (C.c_int, [_H, C.c_int, C.c_char_p, C.c_int]),
     "spmv_csr_time": (C.c_int, [_H, C.c_int, _f32p, _f32p, C.c_int, _vp, C.POINTER(C.c_float)]),
     "spmv_csr_run_host": (C.c_int, [_H, C.c_int, _f32p, _f32p, C.POINTER(C.c_float)]),
     "spmv_dense_gemv": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _vp]),
@@ -186,6 +187,11 @@ class CsrMatrix:
         ms = C.c_float()
         check(lib().spmv_csr_run_host(self._h, variant, _ptr(x), _ptr(y), C.byref(ms)))
         return ms.value
+
+    def plan_describe(self, variant: int) -> str:
+        buf = C.create_string_buffer(256)
+        check(lib().spmv_csr_plan_describe(self._h, variant, buf, 256))
+        return buf.value.decode()
 
     def plan_bytes(self, variant: int) -> int:
         return lib().spmv_csr_plan_bytes(self._h, variant)

@@ -249,10 +249,26 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
     switch (variant) {
         case SPMV_ADAPTIVE:  // chunk_lb read + carry written and re-read
             return (int64_t)(h->plan_adaptive.nchunks + 1) * 4 + (int64_t)h->plan_adaptive.nchunks * 8;
-        case SPMV_TILED:     // + the two window words per chunk
-            return (int64_t)(h->plan_tiled.nchunks + 1) * 4 + (int64_t)h->plan_tiled.nchunks * 16;
+        case SPMV_TILED:     // + the two window words per chunk, the chunk lists and the 16-bit offsets
+            return (int64_t)(h->plan_tiled.nchunks + 1) * 4 + (int64_t)h->plan_tiled.nchunks * 16 +
+                   (h->plan_tiled.d_col16 ? (int64_t)h->plan_tiled.nchunks * 4 +
+                                                (int64_t)h->plan_tiled.n16 * 2 * h->plan_tiled.block * kNnzPerThread
+                                          : 0);
         default: return 0;
     }
+}
+
+int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
+{
+    if (!h || !buf || n <= 0) { set_error("spmv_csr_plan_describe: bad argument"); return SPMV_ERR_INVALID; }
+    const ChunkPlan *p = variant == SPMV_ADAPTIVE ? &h->plan_adaptive : (variant == SPMV_TILED ? &h->plan_tiled : nullptr);
+    if (variant == SPMV_VECTOR) snprintf(buf, (size_t)n, "lanes_per_row=%d", h->vector_width);
+    else if (!p) snprintf(buf, (size_t)n, "no plan");
+    else if (!p->block) snprintf(buf, (size_t)n, "not planned");
+    else
+        snprintf(buf, (size_t)n, "block=%d maxpass=%d chunks=%d staged_single=%d staged_full=%d col16_chunks=%d persist=%d",
+                 p->block, p->maxpass, p->nchunks, p->staged_single, p->staged_full, p->n16, p->persist ? 1 : 0);
+    return SPMV_OK;
 }
 
 int spmv_csr_time(spmv_csr_t *h, int variant, const float *d_x, float *d_y, int iters, void *stream,

@@ -93,6 +93,8 @@ __global__ void k_plan_chunks(int64_t rows, int nchunks, int chunk, const int32_
 // nonzeros.  stats[0] = chunks staged in a single pass with nothing outside, stats[1] = chunks
 // staged completely (any number of passes).
 constexpr int kOutsideBit = 1 << 30;
+constexpr int kCol16Bit = 1 << 29;   // the chunk's columns also exist as 16-bit offsets from w0 (plan.d_col16)
+constexpr int kLenMask = kCol16Bit - 1;
 
 __global__ __launch_bounds__(256) void k_plan_windows(int64_t nnz, int64_t cols, int nchunks, int chunk,
                                                       const int32_t *__restrict__ col_idx,
@@ -189,6 +191,85 @@ __device__ __forceinline__ Segment make_segment(int t, int lb0, int64_t base, in
     return g;
 }
 
+// Static LDS of a workgroup besides the dynamic region.
+template <int BLOCK>
+struct ChunkShared {
+    int2 long_seg[max_long(BLOCK)];  // {segment id, first product | end product << 16}
+    int2 huge_seg[max_huge(BLOCK)];
+    float wave_part[BLOCK / kWave];
+    int long_count, huge_count;
+};
+
+// The row reduction of one chunk, products already staged in `smem` (a barrier behind them):
+//   short segments (<= kShortSeg): one lane each, sequential (the oracle's order);
+//   17..kHugeSeg: queued in LDS with their bounds, summed by kGroup-lane groups (__shfl_down tree);
+//   longer (a power-law row can fill the chunk): the whole workgroup.
+// PREF: this lane's first row bounds were prefetched into rb0/re0.
+template <int BLOCK, bool PREF>
+__device__ __forceinline__ void reduce_chunk(const float *smem, ChunkShared<BLOCK> &sh, int tid, int c, int lb0, int m,
+                                             int64_t base, int64_t lim, const int32_t *__restrict__ row_ptr,
+                                             float *__restrict__ y, float *__restrict__ carry, int32_t rb0, int32_t re0)
+{
+    for (int t = tid; t <= m; t += BLOCK) {
+        int32_t rb, re;
+        if (PREF && t == tid) { rb = rb0; re = re0; }
+        else { rb = row_ptr[t == 0 ? lb0 : lb0 + t - 1]; re = t == 0 ? 0 : row_ptr[lb0 + t]; }
+        const Segment g = make_segment(t, lb0, base, lim, rb, re, y, carry, c);
+        if (g.e - g.s <= kShortSeg) {
+            float acc = 0.0f;
+            int i = g.s;
+            for (; i + 3 < g.e; i += 4) {
+                const float a0 = smem[pad_idx(i)], a1 = smem[pad_idx(i + 1)], a2 = smem[pad_idx(i + 2)],
+                            a3 = smem[pad_idx(i + 3)];
+                acc = (((acc + a0) + a1) + a2) + a3;
+            }
+            for (; i < g.e; ++i) acc += smem[pad_idx(i)];
+            *g.dst = acc;
+        } else if (g.e - g.s <= kHugeSeg) {
+            const int slot = atomicAdd(&sh.long_count, 1);
+            sh.long_seg[slot] = make_int2(t, g.s | (g.e << 16));  // s < 2^14, e <= 2^14
+        } else {
+            const int slot = atomicAdd(&sh.huge_count, 1);
+            sh.huge_seg[slot] = make_int2(t, g.s | (g.e << 16));
+        }
+    }
+    __syncthreads();
+
+    const int nlong = sh.long_count;
+    const int sub = tid & (kGroup - 1);
+    for (int i = tid / kGroup; i < nlong; i += BLOCK / kGroup) {
+        const int2 q = sh.long_seg[i];
+        const int qe = (int)((unsigned)q.y >> 16);
+        float acc = 0.0f;
+        for (int k = (q.y & 0xffff) + sub; k < qe; k += kGroup) acc += smem[pad_idx(k)];
+#pragma unroll
+        for (int o = kGroup / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kGroup);
+        if (sub == 0) {
+            if (q.x == 0) carry[c] = acc;
+            else y[(int64_t)lb0 + q.x - 1] = acc;
+        }
+    }
+
+    const int nhuge = sh.huge_count;
+    for (int i = 0; i < nhuge; ++i) {
+        const int2 q = sh.huge_seg[i];
+        const int qe = (int)((unsigned)q.y >> 16);
+        float acc = 0.0f;
+        for (int k = (q.y & 0xffff) + tid; k < qe; k += BLOCK) acc += smem[pad_idx(k)];
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+        if ((tid & (kWave - 1)) == 0) sh.wave_part[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.0f;
+            for (int w = 0; w < BLOCK / kWave; ++w) tot += sh.wave_part[w];
+            if (q.x == 0) carry[c] = tot;
+            else y[(int64_t)lb0 + q.x - 1] = tot;
+        }
+        __syncthreads();
+    }
+}
+
 // The stream of one chunk: 16 B per lane per load (1 KiB contiguous per wave instruction),
 // non-temporal (read once), all 8 loads issued back to back.
 template <int BLOCK, bool FULL_ONLY>
@@ -267,7 +348,8 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
                                                        const float *__restrict__ x, float *__restrict__ y,
                                                        const int32_t *__restrict__ chunk_lb,
                                                        float *__restrict__ carry,
-                                                       const int32_t *__restrict__ win)
+                                                       const int32_t *__restrict__ win,
+                                                       const int32_t *__restrict__ list)
 {
     constexpr int kChunkT = chunk_of(BLOCK);
     constexpr int kVec = kNnzPerThread / 4;
@@ -275,16 +357,18 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
     // one dynamic LDS region, used twice: first as the x window (TILED), then -- after the
     // gathers have landed in registers -- as the product staging buffer.
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int2 long_seg[max_long(BLOCK)];  // {segment id, first product | end product << 16}
-    __shared__ int2 huge_seg[max_huge(BLOCK)];
-    __shared__ float wave_part[BLOCK / kWave];
-    __shared__ int long_count, huge_count;
+    __shared__ ChunkShared<BLOCK> sh;
 
     const int tid0 = threadIdx.x;
     Walk wk = first_chunk(PERSIST, blockIdx.x, gridDim.x, nrun);
     if (wk.c >= wk.end) return;
-    wk.c += chunk0;
-    wk.end += chunk0;
+    if (!PERSIST && list) {  // one-shot launch over a chunk list (the chunks without 16-bit columns)
+        wk.c = list[wk.c];
+        wk.end = wk.c + 1;
+    } else {
+        wk.c += chunk0;
+        wk.end += chunk0;
+    }
 
     i4 cc[kVec];
     f4 vv[kVec];
@@ -303,7 +387,7 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
         const int64_t base = (int64_t)c * kChunkT;
         const int n = (int)((nnz - base) < kChunkT ? (nnz - base) : kChunkT);
         const int64_t lim = base + n;
-        if (tid == 0) { long_count = 0; huge_count = 0; }
+        if (tid == 0) { sh.long_count = 0; sh.huge_count = 0; }
 
         const int lb0 = chunk_lb[c], lb1 = chunk_lb[c + 1];
         const int m = lb1 - lb0;
@@ -312,7 +396,7 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
         if (TILED) {
             w0 = win[2 * c];
             const int wl = win[2 * c + 1];
-            wlen = wl & (kOutsideBit - 1);
+            wlen = wl & kLenMask;
             outside = (wl & kOutsideBit) != 0;
         }
 
@@ -390,75 +474,153 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
         }
         __syncthreads();
 
-        // ---- short segments: one lane each, sequential (the oracle's order); longer ones are
-        //      queued in LDS with their bounds so that the later phases touch no global metadata
-        for (int t = tid; t <= m; t += BLOCK) {
-            int32_t rb, re;
-            if (!TILED && t == tid) { rb = rb0; re = re0; }
-            else { rb = row_ptr[t == 0 ? lb0 : lb0 + t - 1]; re = t == 0 ? 0 : row_ptr[lb0 + t]; }
-            const Segment g = make_segment(t, lb0, base, lim, rb, re, y, carry, c);
-            if (g.e - g.s <= kShortSeg) {
-                float acc = 0.0f;
-                int i = g.s;
-                for (; i + 3 < g.e; i += 4) {
-                    const float a0 = smem[pad_idx(i)], a1 = smem[pad_idx(i + 1)], a2 = smem[pad_idx(i + 2)],
-                                a3 = smem[pad_idx(i + 3)];
-                    acc = (((acc + a0) + a1) + a2) + a3;
-                }
-                for (; i < g.e; ++i) acc += smem[pad_idx(i)];
-                *g.dst = acc;
-            } else if (g.e - g.s <= kHugeSeg) {
-                const int slot = atomicAdd(&long_count, 1);
-                long_seg[slot] = make_int2(t, g.s | (g.e << 16));  // s < 2^14, e <= 2^14
-            } else {
-                const int slot = atomicAdd(&huge_count, 1);
-                huge_seg[slot] = make_int2(t, g.s | (g.e << 16));
-            }
-        }
-        __syncthreads();
-
-        // ---- long segments: one kGroup-lane group each (BLOCK/kGroup in parallel), lanes stride
-        //      the segment, __shfl_down tree inside the group
-        const int nlong = long_count;
-        const int sub = tid & (kGroup - 1);
-        for (int i = tid / kGroup; i < nlong; i += BLOCK / kGroup) {
-            const int2 q = long_seg[i];
-            const int qe = (int)((unsigned)q.y >> 16);
-            float acc = 0.0f;
-            for (int k = (q.y & 0xffff) + sub; k < qe; k += kGroup) acc += smem[pad_idx(k)];
-#pragma unroll
-            for (int o = kGroup / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kGroup);
-            if (sub == 0) {
-                if (q.x == 0) carry[c] = acc;
-                else y[(int64_t)lb0 + q.x - 1] = acc;
-            }
-        }
-
-        // ---- huge segments (a power-law row can fill the whole chunk): the whole workgroup
-        //      strides one segment, wavefront trees, then the per-wave partials in wave order
-        const int nhuge = huge_count;
-        for (int i = 0; i < nhuge; ++i) {
-            const int2 q = huge_seg[i];
-            const int qe = (int)((unsigned)q.y >> 16);
-            float acc = 0.0f;
-            for (int k = (q.y & 0xffff) + tid; k < qe; k += BLOCK) acc += smem[pad_idx(k)];
-#pragma unroll
-            for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
-            if ((tid & (kWave - 1)) == 0) wave_part[tid >> 6] = acc;
-            __syncthreads();
-            if (tid == 0) {
-                float tot = 0.0f;
-                for (int w = 0; w < BLOCK / kWave; ++w) tot += wave_part[w];
-                if (q.x == 0) carry[c] = tot;
-                else y[(int64_t)lb0 + q.x - 1] = tot;
-            }
-            __syncthreads();
-        }
+        // ---- rows of this chunk
+        reduce_chunk<BLOCK, !TILED>(smem, sh, tid, c, lb0, m, base, lim, row_ptr, y, carry, rb0, re0);
 
         if (!more) break;
         __syncthreads();  // the region and the queues are reused by the next chunk
         wk.c = cn;
     }
+}
+
+// ---------------------------------------------------------------------------
+// 16-bit columns.  A chunk whose whole column span is staged in LDS never needs absolute columns:
+// the plan stores col - w0 as uint16 (span < 65536), laid out so that each lane's 16 offsets are
+// two 16-byte loads, and k_tiled16 streams 6 bytes per nonzero instead of 8 (HBM traffic of config 4:
+// 1.8 GB against 2.35 GB algorithmic).  One-shot workgroups over the list of such chunks; the others
+// (outliers gathered from global memory, the ragged last chunk) go through k_adaptive.
+using u4 = unsigned __attribute__((ext_vector_type(4)));
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols, int nrun,
+                                                      const int32_t *__restrict__ row_ptr,
+                                                      const uint16_t *__restrict__ col16,
+                                                      const float *__restrict__ vals,
+                                                      const float *__restrict__ x, float *__restrict__ y,
+                                                      const int32_t *__restrict__ chunk_lb,
+                                                      float *__restrict__ carry,
+                                                      const int32_t *__restrict__ win,
+                                                      const int32_t *__restrict__ list)
+{
+    constexpr int kChunkT = chunk_of(BLOCK);
+    constexpr int kVec = kNnzPerThread / 4;
+    constexpr int kRegion = region_words(BLOCK);
+    static_assert(kNnzPerThread == 16, "the col16 lane layout is two 16-byte loads of eight offsets");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ ChunkShared<BLOCK> sh;
+
+    const int tid = threadIdx.x;
+    const int c = list[xcd_chunk(blockIdx.x, nrun)];
+    const int64_t base = (int64_t)c * kChunkT;
+    const int64_t lim = base + kChunkT;
+    if (tid == 0) { sh.long_count = 0; sh.huge_count = 0; }
+    const int lb0 = chunk_lb[c], lb1 = chunk_lb[c + 1];
+    const int m = lb1 - lb0;
+    const int w0 = win[2 * c];
+    const int wlen = win[2 * c + 1] & kLenMask;
+
+    // ---- stream: 2 x 16 B of offsets + 4 x 16 B of values per lane, non-temporal
+    u4 raw[2];
+    f4 vv[kVec];
+    {
+        const u4 *c8 = reinterpret_cast<const u4 *>(col16 + base);
+        const f4 *v4 = reinterpret_cast<const f4 *>(vals + base);
+        raw[0] = __builtin_nontemporal_load(&c8[tid]);
+        raw[1] = __builtin_nontemporal_load(&c8[BLOCK + tid]);
+#pragma unroll
+        for (int j = 0; j < kVec; ++j) vv[j] = __builtin_nontemporal_load(&v4[j * BLOCK + tid]);
+    }
+
+    // ---- gather x from the staged slices (every column of the chunk lies in [w0, w0+wlen))
+    f4 xv[kVec];
+#pragma unroll
+    for (int j = 0; j < kVec; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[j][q] = 0.0f;
+    for (int off = 0; off < wlen; off += kRegion) {
+        const int len = (wlen - off) < kRegion ? (wlen - off) : kRegion;
+        const int64_t g0 = (int64_t)w0 + off;
+        for (int i = tid * 4; i < len; i += BLOCK * 4) {
+            if (g0 + i + 3 < cols) {
+                *reinterpret_cast<f4 *>(smem + i) = *reinterpret_cast<const f4 *>(x + g0 + i);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (g0 + i + q < cols) smem[i + q] = x[g0 + i + q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kVec; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // element (j, q) of this lane is offset e = (j&1)*4 + q of load j>>1
+                const int e = (j & 1) * 4 + q;
+                const unsigned word = raw[j >> 1][e >> 1];
+                const unsigned cl = (e & 1) ? (word >> 16) : (word & 0xffffu);
+                const unsigned o = cl - (unsigned)off;
+                if (o < (unsigned)len) xv[j][q] = smem[o];
+            }
+        __syncthreads();  // every gather has its value before the slice is overwritten
+    }
+
+    // ---- products, then the rows of the chunk
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+        const int p0 = pad_idx((j * BLOCK + tid) * 4);
+        smem[p0] = vv[j][0] * xv[j][0];
+        smem[p0 + 1] = vv[j][1] * xv[j][1];
+        smem[p0 + 2] = vv[j][2] * xv[j][2];
+        smem[p0 + 3] = vv[j][3] * xv[j][3];
+    }
+    __syncthreads();
+    reduce_chunk<BLOCK, false>(smem, sh, tid, c, lb0, m, base, lim, row_ptr, y, carry, 0, 0);
+}
+
+// plan: 16-bit offsets of every eligible chunk (full chunk, whole span staged, span < 65536), in the
+// lane layout of k_tiled16; flags[c] = 1 for those chunks and kCol16Bit is set in win[2c+1].
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t *__restrict__ col_idx,
+                                                      int32_t *__restrict__ win, uint16_t *__restrict__ col16,
+                                                      int32_t *__restrict__ flags)
+{
+    constexpr int kChunkT = chunk_of(BLOCK);
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int64_t base = (int64_t)c * kChunkT;
+    const int wl = win[2 * c + 1];
+    const int wlen = wl & kLenMask;
+    const bool ok = (nnz - base) >= kChunkT && wlen > 0 && wlen < 65536 && !(wl & kOutsideBit);
+    __syncthreads();  // everyone has read win before lane 0 rewrites it
+    if (tid == 0) {
+        flags[c] = ok ? 1 : 0;
+        if (ok) win[2 * c + 1] = wl | kCol16Bit;
+    }
+    if (!ok) return;
+    const int w0 = win[2 * c];
+    u4 *out = reinterpret_cast<u4 *>(col16 + base);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        unsigned v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 2 * k + (e >> 2), q = e & 3;
+            v[e] = (unsigned)(col_idx[base + (j * BLOCK + tid) * 4 + q] - w0);
+        }
+        u4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = v[2 * i] | (v[2 * i + 1] << 16);
+        out[k * BLOCK + tid] = w;
+    }
+}
+
+// plan: chunk lists from the exclusive scan of flags: list16[pos[c]] = c, list32[c - pos[c]] = c
+__global__ void k_plan_lists(int nchunks, const int32_t *__restrict__ flags, const int32_t *__restrict__ pos,
+                             int32_t *__restrict__ list16, int32_t *__restrict__ list32)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    if (flags[c]) list16[pos[c]] = c;
+    else list32[c - pos[c]] = c;
 }
 
 // rows that continue past their owner chunk: y[r] += carry[c+1] + carry[c+2] + ... in chunk order
@@ -491,6 +653,9 @@ static void free_plan(ChunkPlan &p)
     if (p.d_lb) (void)hipFree(p.d_lb);
     if (p.d_carry) (void)hipFree(p.d_carry);
     if (p.d_win) (void)hipFree(p.d_win);
+    if (p.d_col16) (void)hipFree(p.d_col16);
+    if (p.d_list16) (void)hipFree(p.d_list16);
+    if (p.d_list32) (void)hipFree(p.d_list32);
     p = ChunkPlan();
 }
 
@@ -502,6 +667,7 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
     const bool windows = maxpass > 0;
     free_plan(p);
     p.block = block;
+    p.maxpass = maxpass;
     // tuning knob SPMV_PERSIST=0|1, read when the plan is made (default 0: the persistent form
     // needs 80 VGPRs -> 6 waves/SIMD, and lost 7-40 % against 8 waves/SIMD one-shot workgroups)
     if (const char *e = getenv("SPMV_PERSIST")) p.persist = atoi(e) != 0;
@@ -535,6 +701,52 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
     return SPMV_OK;
 }
 
+template <int BLOCK>
+static int launch_plan_col16(const spmv_csr &h, ChunkPlan &p, int32_t *d_flags, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_plan_col16<BLOCK>), dim3(p.nchunks), dim3(BLOCK), 0, s, h.nnz, h.d_col_idx, p.d_win, p.d_col16,
+                       d_flags);
+    return check_launch("k_plan_col16");
+}
+
+// 16-bit column offsets + the two chunk lists for a finished TILED plan
+static int build_col16(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
+{
+    if (p.nchunks == 0 || !p.d_win || p.persist) return SPMV_OK;
+    if (const char *e = getenv("SPMV_COL16")) {  // tuning knob: 0 keeps 32-bit columns everywhere
+        if (atoi(e) == 0) return SPMV_OK;
+    }
+    const size_t chunk = (size_t)chunk_of(p.block);
+    DevPtr<int32_t> flags, pos, total;
+    SPMV_HIP_TRY(flags.alloc((size_t)p.nchunks));
+    SPMV_HIP_TRY(pos.alloc((size_t)p.nchunks));
+    SPMV_HIP_TRY(total.alloc(1));
+    SPMV_HIP_TRY(hipMalloc((void **)&p.d_col16, sizeof(uint16_t) * chunk * (size_t)p.nchunks));
+    SPMV_HIP_TRY(hipMalloc((void **)&p.d_list16, sizeof(int32_t) * (size_t)p.nchunks));
+    SPMV_HIP_TRY(hipMalloc((void **)&p.d_list32, sizeof(int32_t) * (size_t)p.nchunks));
+    int rc;
+    if (p.block == 256) rc = launch_plan_col16<256>(h, p, flags.p, s);
+    else if (p.block == 512) rc = launch_plan_col16<512>(h, p, flags.p, s);
+    else rc = launch_plan_col16<1024>(h, p, flags.p, s);
+    if (rc) return rc;
+    SPMV_HIP_TRY(hipMemcpyAsync(pos.p, flags.p, sizeof(int32_t) * (size_t)p.nchunks, hipMemcpyDeviceToDevice, s));
+    if ((rc = exclusive_scan_i32(pos.p, p.nchunks, total.p, s))) return rc;
+    hipLaunchKernelGGL(k_plan_lists, dim3((p.nchunks + 255) / 256), dim3(256), 0, s, p.nchunks, flags.p, pos.p, p.d_list16,
+                       p.d_list32);
+    if ((rc = check_launch("k_plan_lists"))) return rc;
+    int32_t n16 = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&n16, total.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    p.n16 = n16;
+    if (2 * (int64_t)n16 < p.nchunks) {  // too few eligible chunks to pay for a second launch: 32-bit path
+        p.n16 = 0;
+        (void)hipFree(p.d_col16); p.d_col16 = nullptr;
+        (void)hipFree(p.d_list16); p.d_list16 = nullptr;
+        (void)hipFree(p.d_list32); p.d_list32 = nullptr;
+    }
+    return SPMV_OK;
+}
+
 int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s);
 
 int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
@@ -551,7 +763,10 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
     if (forced != 256 && forced != 512 && forced != 1024) forced = 0;
     if (const char *e = getenv("SPMV_MAXPASS")) forced_pass = atoi(e);
     if (forced_pass < 1 || forced_pass > 64) forced_pass = 0;
-    if (forced) return build_plan(h, forced, forced_pass ? forced_pass : default_passes(forced), s, h.plan_tiled, nullptr, nullptr);
+    if (forced) {
+        int rc = build_plan(h, forced, forced_pass ? forced_pass : default_passes(forced), s, h.plan_tiled, nullptr, nullptr);
+        return rc ? rc : build_col16(h, h.plan_tiled, s);
+    }
 
     bool autotune = h.nnz >= (1 << 20);  // below ~1M nonzeros a launch is a few microseconds either way
     if (const char *e = getenv("SPMV_AUTOTUNE")) autotune = atoi(e) != 0;
@@ -566,16 +781,18 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
             int single = 0, full = 0;
             int rc = build_plan(h, cands[k], default_passes(cands[k]), s, h.plan_tiled, &single, &full);
             if (rc) return rc;
-            if (h.plan_tiled.nchunks == 0 || single >= 0.9 * h.plan_tiled.nchunks) return SPMV_OK;
+            if (h.plan_tiled.nchunks == 0 || single >= 0.9 * h.plan_tiled.nchunks) return build_col16(h, h.plan_tiled, s);
             full1024 = full;
         }
-        if (full1024 >= 0.5 * h.plan_tiled.nchunks) return SPMV_OK;
-        return build_plan(h, 256, default_passes(256), s, h.plan_tiled, nullptr, nullptr);
+        if (full1024 >= 0.5 * h.plan_tiled.nchunks) return build_col16(h, h.plan_tiled, s);
+        int rc = build_plan(h, 256, default_passes(256), s, h.plan_tiled, nullptr, nullptr);
+        return rc ? rc : build_col16(h, h.plan_tiled, s);
     }
 
     // Autotune (the default for real sizes): the best (workgroup size, pass budget) depends on how the
-    // column spans are distributed -- a band, a band plus a few long rows, power-law rows -- so the
-    // plan times the kernel itself on the candidates and keeps the fastest.  Costs a few launches,
+    // column spans are distributed -- a band, a band plus a few long rows, power-law rows -- and on
+    // how many chunks end up with 16-bit columns, so the plan times the kernels themselves on the
+    // candidates and keeps the fastest.  Costs a few launches,
     // once per matrix (the reference pays a host-side format build per launcher call).
     struct Cand { int block, maxpass; };
     const Cand cands[] = {{256, 2}, {512, 4}, {512, 8}, {1024, 6}, {1024, 12}};
@@ -594,6 +811,7 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
         int single = 0, full = 0;
         if ((rc = build_plan(h, c.block, c.maxpass, s, p, &single, &full))) break;
         if (p.nchunks == 0) { best = p; p = ChunkPlan(); break; }
+        if ((rc = build_col16(h, p, s))) break;  // time what will actually run
         if ((rc = launch_adaptive(h, xt.p, yt.p, true, s))) break;  // warm (code object, attribute)
         hipEventRecord(e0, s);
         for (int i = 0; i < 3 && rc == SPMV_OK; ++i) rc = launch_adaptive(h, xt.p, yt.p, true, s);
@@ -641,7 +859,7 @@ static int resident_workgroups(int block, int waves_simd)
 
 template <int BLOCK, bool TILED, bool PERSIST>
 static int launch_range(const spmv_csr &h, const ChunkPlan &p, int chunk0, int nrun, const float *x, float *y,
-                        hipStream_t s)
+                        hipStream_t s, const int32_t *list = nullptr)
 {
     if (nrun <= 0) return SPMV_OK;
     // dynamic LDS: the product buffer; a staged x slice is never wider (plan cap = region)
@@ -658,13 +876,35 @@ static int launch_range(const spmv_csr &h, const ChunkPlan &p, int chunk0, int n
         if (grid > res) grid = res;
     }
     hipLaunchKernelGGL((k_adaptive<BLOCK, TILED, PERSIST>), dim3(grid), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols,
-                       chunk0, nrun, h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win);
+                       chunk0, nrun, h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, list);
     return check_launch("k_adaptive");
+}
+
+template <int BLOCK>
+static int launch_tiled16(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
+{
+    if (p.n16 <= 0) return SPMV_OK;
+    const size_t lds = sizeof(float) * (size_t)region_words(BLOCK);
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
+        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiled16<BLOCK>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_tiled16<BLOCK>), dim3(p.n16), dim3(BLOCK), lds, s, h.rows, h.cols, p.n16, h.d_row_ptr,
+                       p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, p.d_list16);
+    return check_launch("k_tiled16");
 }
 
 template <int BLOCK, bool TILED>
 static int launch_either(bool persist, const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
 {
+    if (TILED && !persist && p.d_col16) {
+        // the chunks with 16-bit columns, then the others through the 32-bit kernel
+        int rc = launch_tiled16<BLOCK>(h, p, x, y, s);
+        if (rc == SPMV_OK) rc = launch_range<BLOCK, TILED, false>(h, p, 0, p.nchunks - p.n16, x, y, s, p.d_list32);
+        return rc;
+    }
     if (!persist) return launch_range<BLOCK, TILED, false>(h, p, 0, p.nchunks, x, y, s);
     // persistent launch over the full chunks, one-shot launch for a trailing partial chunk
     const int nfull = (int)(h.nnz / chunk_of(BLOCK));

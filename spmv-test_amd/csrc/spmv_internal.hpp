@@ -53,6 +53,12 @@ struct ChunkPlan {
     int32_t *d_lb = nullptr;   // [nchunks+1] first row whose row_ptr >= c*chunk
     float *d_carry = nullptr;  // [nchunks]   partial sum of the row continued from chunk c-1
     int32_t *d_win = nullptr;  // [2*nchunks+2] TILED: first column, window length (0 = not staged); stats
+    // 16-bit columns (TILED): chunks whose span is fully staged also carry col - w0 as uint16
+    uint16_t *d_col16 = nullptr;   // [nchunks * chunk], lane layout of k_tiled16
+    int32_t *d_list16 = nullptr;   // [n16] chunks run by k_tiled16
+    int32_t *d_list32 = nullptr;   // [nchunks - n16] the others, run by k_adaptive
+    int n16 = 0;
+    int maxpass = 0;
     bool persist = false;      // persistent software-pipelined launch (measured slower: DESIGN.md section 4)
     int staged_single = 0;     // TILED: chunks whose whole column span is staged in one pass
     int staged_full = 0;       // TILED: chunks staged completely (any number of passes)

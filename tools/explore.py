@@ -51,7 +51,8 @@ def main():
             A.time(v, d_x, d_y, 3)
             ms = min(A.time(v, d_x, d_y, e.get("iters", 30)) for _ in range(3))
             print(json.dumps(dict(dist=e["dist"], band=e["band"], rows=rows, variant=vname, env=e.get("env", {}), lib=e.get("lib", ""),
-                                  ms=round(ms, 4), GBs=round(B / ms / 1e6, 1), pct=round(B / ms / 1e6 / 80, 2))), flush=True)
+                                  ms=round(ms, 4), GBs=round(B / ms / 1e6, 1), pct=round(B / ms / 1e6 / 80, 2),
+                                  plan=A.plan_describe(v))), flush=True)
         A.close()
 
 

@@ -1,0 +1,96 @@
+// tools/ubench_panel.hip -- development micro-benchmark: would a 2-D (row block x column panel) sweep
+// make uniform-random columns L2-resident?  One workgroup per row block of RB rows keeps its y block in
+// LDS and walks the column panels in order; all workgroups of an XCD walk in rough lockstep, so the XCD's
+// L2 should hold the panel of x they are all gathering from.  Synthetic tiles: T nonzeros per (row block,
+// panel), packed {row_local:14 | col_local:18}, random.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_panel.hip -o tools/bin/ubench_panel
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP %s @%d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+__device__ __forceinline__ uint64_t mix64(uint64_t z) { z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31; return z; }
+using u4 = unsigned __attribute__((ext_vector_type(4)));
+using f4 = float __attribute__((ext_vector_type(4)));
+
+__global__ void k_gen(int64_t n, int rb_rows, int pcols, unsigned* packed, float* val) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h = mix64(i * 0x9E3779B97F4A7C15ull + 7);
+    unsigned row = (unsigned)(h % (unsigned)rb_rows);   // any row of the block
+    unsigned col = (unsigned)((h >> 20) % (unsigned)pcols);
+    packed[i] = (row << 18) | col;
+    val[i] = (float)((int)(h & 0xFFFF) - 32768) * (1.0f / 32768.0f);
+}
+__global__ void k_fill(int64_t n, float* x) { int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) x[i] = 1.0f + (float)(i & 7); }
+
+// BLK threads, RB rows per block (y block in LDS), NP panels, T = 4096 nonzeros per tile
+template <int BLK, int RB, int T>
+__global__ __launch_bounds__(BLK) void k_panel(int np, int pcols, const unsigned* __restrict__ packed, const float* __restrict__ val,
+                                               const float* __restrict__ x, float* __restrict__ y, int swizzle) {
+    __shared__ float ys[RB];
+    const int tid = threadIdx.x;
+    int rb = blockIdx.x;
+    if (swizzle) {  // XCD-contiguous row blocks
+        const int n = gridDim.x, q = n / 8, j = rb % 8, idx = rb / 8;
+        rb = j * q + idx;
+    }
+    for (int i = tid; i < RB; i += BLK) ys[i] = 0.f;
+    __syncthreads();
+    constexpr int V = T / BLK / 4;
+    for (int p = 0; p < np; ++p) {
+        const int64_t base = ((int64_t)rb * np + p) * T;
+        const u4* c4 = reinterpret_cast<const u4*>(packed + base);
+        const f4* v4 = reinterpret_cast<const f4*>(val + base);
+        const float* xp = x + (int64_t)p * pcols;
+        u4 cc[V]; f4 vv[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { cc[j] = __builtin_nontemporal_load(&c4[j * BLK + tid]); vv[j] = __builtin_nontemporal_load(&v4[j * BLK + tid]); }
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float xv = xp[cc[j][q] & 0x3FFFF];
+                atomicAdd(&ys[cc[j][q] >> 18], vv[j][q] * xv);
+            }
+    }
+    __syncthreads();
+    for (int i = tid; i < RB; i += BLK) y[(int64_t)rb * RB + i] = ys[i];
+}
+
+template <typename F> float timeit(F f, int iters) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) f();
+    CK(hipEventRecord(a)); for (int i = 0; i < iters; ++i) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); CK(hipGetLastError()); return ms / iters;
+}
+
+template <int BLK, int RB, int T>
+void run(int64_t rows, int64_t cols, int64_t nnz, unsigned* packed, float* val, float* x, float* y) {
+    const int nrb = rows / RB;
+    const int np = (int)(nnz / nrb / T);
+    const int pcols = (int)(cols / np);
+    k_gen<<<(nnz + 255) / 256, 256>>>(nnz, RB, pcols, packed, val);   // rows sorted inside each T-tile
+    CK(hipDeviceSynchronize());
+    const double bytes_alg = 8.0 * nnz + 4.0 * (rows + 1) + 4.0 * rows + 4.0 * cols;
+    float ms = timeit([&] { k_panel<BLK, RB, T><<<nrb, BLK>>>(np, pcols, packed, val, x, y, 1); }, 5);
+    printf("BLK=%4d RB=%5d T=%4d panels=%3d (x slice %4d KiB)  %.4f ms  %.0f GB/s  %.1f%% of peak\n", BLK, RB, T, np, pcols * 4 / 1024, ms,
+           bytes_alg / ms / 1e6, bytes_alg / ms / 1e6 / 80);
+}
+
+int main(int argc, char** argv) {
+    const int64_t rows = 1ll << 24, cols = rows, nnz = rows * 16;
+    unsigned* packed; float *val, *x, *y;
+    CK(hipMalloc(&packed, nnz * 4)); CK(hipMalloc(&val, nnz * 4)); CK(hipMalloc(&x, cols * 4)); CK(hipMalloc(&y, rows * 4));
+    k_fill<<<(cols + 255) / 256, 256>>>(cols, x);
+    run<512, 16384, 4096>(rows, cols, nnz, packed, val, x, y);
+    run<256, 8192, 4096>(rows, cols, nnz, packed, val, x, y);
+    run<512, 8192, 4096>(rows, cols, nnz, packed, val, x, y);
+    run<256, 8192, 2048>(rows, cols, nnz, packed, val, x, y);
+    run<512, 8192, 2048>(rows, cols, nnz, packed, val, x, y);
+    run<256, 4096, 2048>(rows, cols, nnz, packed, val, x, y);
+    run<256, 4096, 1024>(rows, cols, nnz, packed, val, x, y);
+    run<256, 8192, 1024>(rows, cols, nnz, packed, val, x, y);
+    run<256, 16384, 2048>(rows, cols, nnz, packed, val, x, y);
+    return 0;
+}
