@@ -229,7 +229,8 @@ def main():
             "gflops": round(gflops, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_adaptive" if args.variant in ("adaptive", "tiled") else f"k_{args.variant}",
+                         "kernel": ("k_tiled16" if args.variant == "tiled" and "col16_chunks=0 " not in handles[0].plan_describe(variant)
+                                    else "k_adaptive" if args.variant in ("adaptive", "tiled") else f"k_{args.variant}"),
                          "kernel_ms": round(kernel_ms, 5), "timing": "HIP events on the launch stream"},
             "step_ms_events": round(step_ms_events, 5), "multiply_only_ms": round(kernel_ms, 5),
             "plan_ms": round(plan_ms, 4), "plan_bytes": sum(h.plan_bytes(variant) for h in handles),

@@ -62,7 +62,7 @@ def main():
         kernels[k] = {"launches": n, "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
                       "hbm_bytes_per_launch": int(round((2 * f_kib + w_kib) * 1024))}
     # the plan autotunes over several instantiations of k_adaptive: the timed one has the most launches
-    dom = max((k for k in kernels if "k_adaptive" in k), key=lambda k: kernels[k]["launches"])
+    dom = max((k for k in kernels if "k_adaptive" in k or "k_tiled16" in k), key=lambda k: kernels[k]["launches"])
     summary = {"tag": tag, "command": "python3 bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline",
                "workload": bench["config"]["workload"], "variant": bench["config"]["variant"],
                "calibration": {"kernel": ck, "known_read_bytes": int(known_read), "FETCH_SIZE_KiB": cal_f[ck][0],
