@@ -128,3 +128,36 @@ def test_persistent_launch_knob_gives_the_same_answer(pkg, oracle, gpu, monkeypa
         monkeypatch.setenv("SPMV_TILED_BLOCK", blk)
         p2 = synth_problem(pkg, oracle, gpu, w)
         assert_close_to_oracle(p2.run(pkg.capi.TILED), y64, mag, f"persist/tiled/{blk}")
+
+
+def test_plan_uses_16bit_columns_only_where_the_span_is_staged(pkg, oracle, gpu):
+    """Banded matrix -> (almost) every chunk carries 16-bit offsets; uniform columns -> none; the 32-bit
+    and the 16-bit path agree bit for bit (same products, same order)."""
+    import re
+    W = pkg.workloads
+    wb = W.Workload("t", 32 * W.BLOCK_ROWS, 32 * W.BLOCK_ROWS, "mixed", 16, band=8192)
+    prob = synth_problem(pkg, oracle, gpu, wb)
+    y16 = prob.run(pkg.capi.TILED)
+    desc = prob.A.plan_describe(pkg.capi.TILED)
+    chunks = int(re.search(r"chunks=(\d+)", desc).group(1))
+    n16 = int(re.search(r"col16_chunks=(\d+)", desc).group(1))
+    assert n16 >= 0.9 * chunks, desc
+    y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+    assert_close_to_oracle(y16, y64, mag, "col16")
+
+    os.environ["SPMV_COL16"] = "0"
+    try:
+        p32 = synth_problem(pkg, oracle, gpu, wb)
+        os.environ["SPMV_TILED_BLOCK"] = re.search(r"block=(\d+)", desc).group(1)
+        os.environ["SPMV_MAXPASS"] = re.search(r"maxpass=(\d+)", desc).group(1)
+        y32 = p32.run(pkg.capi.TILED)
+        assert "col16_chunks=0 " in p32.A.plan_describe(pkg.capi.TILED)
+        assert np.array_equal(y16.view(np.uint32), y32.view(np.uint32))
+    finally:
+        for k in ("SPMV_COL16", "SPMV_TILED_BLOCK", "SPMV_MAXPASS"):
+            os.environ.pop(k, None)
+
+    wu = W.Workload("t", 32 * W.BLOCK_ROWS, 32 * W.BLOCK_ROWS, "mixed", 16, band=0)
+    pu = synth_problem(pkg, oracle, gpu, wu)
+    pu.run(pkg.capi.TILED)
+    assert "col16_chunks=0 " in pu.A.plan_describe(pkg.capi.TILED)
