@@ -102,9 +102,13 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
 
 /* ---- the hot path ------------------------------------------------------
  * spmv_csr_plan: one-off device-side preprocessing a variant needs (chunk
- * boundaries, column windows); a no-op for SCALAR/WAVE.  Excluded from the
- * timed SpMV like the reference excludes its host format build from
- * TIME_KERNEL (e.g. wsp.cu:146 vs :167).
+ * boundaries, column windows, for SPMV_TILED also a 16-bit copy of the column
+ * indices and a few timed trial launches that pick the workgroup size); a
+ * no-op for SCALAR/WAVE.  Excluded from the timed SpMV like the reference
+ * excludes its host format build from TIME_KERNEL (e.g. wsp.cu:146 vs :167).
+ * A plan snapshots the sparsity PATTERN (row_ptr, col_idx): with borrowed
+ * arrays (spmv_csr_create_device) the pattern must not change afterwards;
+ * vals are read live on every run and may be updated freely.
  * spmv_csr_run: enqueue y = A x on `stream` (a hipStream_t, NULL = default).
  * Asynchronous; d_x has cols floats, d_y has rows floats and is fully
  * overwritten.  No allocation, no synchronisation: graph-capturable. */
