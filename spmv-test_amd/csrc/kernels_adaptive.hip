@@ -349,11 +349,10 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
                                                        const int32_t *__restrict__ chunk_lb,
                                                        float *__restrict__ carry,
                                                        const int32_t *__restrict__ win,
-                                                       const int32_t *__restrict__ list)
+                                                       const int32_t *__restrict__ list, int kRegion)
 {
     constexpr int kChunkT = chunk_of(BLOCK);
     constexpr int kVec = kNnzPerThread / 4;
-    constexpr int kRegion = region_words(BLOCK);
     // one dynamic LDS region, used twice: first as the x window (TILED), then -- after the
     // gathers have landed in registers -- as the product staging buffer.
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -500,11 +499,10 @@ __global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols
                                                       const int32_t *__restrict__ chunk_lb,
                                                       float *__restrict__ carry,
                                                       const int32_t *__restrict__ win,
-                                                      const int32_t *__restrict__ list)
+                                                      const int32_t *__restrict__ list, int kRegion)
 {
     constexpr int kChunkT = chunk_of(BLOCK);
     constexpr int kVec = kNnzPerThread / 4;
-    constexpr int kRegion = region_words(BLOCK);
     static_assert(kNnzPerThread == 16, "the col16 lane layout is two 16-byte loads of eight offsets");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ ChunkShared<BLOCK> sh;
@@ -668,6 +666,9 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
     free_plan(p);
     p.block = block;
     p.maxpass = maxpass;
+    // LDS region: what 2048 resident threads per CU allow (a 144 KiB region with one 1024-thread
+    // workgroup per CU halves the staging passes of wide spans but measured 25-50 % slower)
+    p.region = region_words(block);
     // tuning knob SPMV_PERSIST=0|1, read when the plan is made (default 0: the persistent form
     // needs 80 VGPRs -> 6 waves/SIMD, and lost 7-40 % against 8 waves/SIMD one-shot workgroups)
     if (const char *e = getenv("SPMV_PERSIST")) p.persist = atoi(e) != 0;
@@ -688,7 +689,7 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
         int32_t *d_stats = p.d_win + 2 * (size_t)p.nchunks;
         SPMV_HIP_TRY(hipMemsetAsync(d_stats, 0, 2 * sizeof(int32_t), s));
         hipLaunchKernelGGL(k_plan_windows, dim3(p.nchunks), dim3(256), 0, s, h.nnz, h.cols, p.nchunks, chunk,
-                           h.d_col_idx, p.d_win, d_stats, region_words(block), maxpass);
+                           h.d_col_idx, p.d_win, d_stats, p.region, maxpass);
         if ((rc = check_launch("k_plan_windows"))) return rc;
         int32_t stats[2] = {0, 0};
         SPMV_HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, s));
@@ -863,7 +864,7 @@ static int launch_range(const spmv_csr &h, const ChunkPlan &p, int chunk0, int n
 {
     if (nrun <= 0) return SPMV_OK;
     // dynamic LDS: the product buffer; a staged x slice is never wider (plan cap = region)
-    const size_t lds = sizeof(float) * (size_t)region_words(BLOCK);
+    const size_t lds = sizeof(float) * (size_t)p.region;
     static std::atomic<bool> attr_set{false};  // > 64 KiB of dynamic LDS needs the opt-in (BLOCK = 1024)
     if (!attr_set.load(std::memory_order_acquire)) {
         SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_adaptive<BLOCK, TILED, PERSIST>),
@@ -876,7 +877,7 @@ static int launch_range(const spmv_csr &h, const ChunkPlan &p, int chunk0, int n
         if (grid > res) grid = res;
     }
     hipLaunchKernelGGL((k_adaptive<BLOCK, TILED, PERSIST>), dim3(grid), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols,
-                       chunk0, nrun, h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, list);
+                       chunk0, nrun, h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, list, p.region);
     return check_launch("k_adaptive");
 }
 
@@ -884,7 +885,7 @@ template <int BLOCK>
 static int launch_tiled16(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
 {
     if (p.n16 <= 0) return SPMV_OK;
-    const size_t lds = sizeof(float) * (size_t)region_words(BLOCK);
+    const size_t lds = sizeof(float) * (size_t)p.region;
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
         SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiled16<BLOCK>),
@@ -892,7 +893,7 @@ static int launch_tiled16(const spmv_csr &h, const ChunkPlan &p, const float *x,
         attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_tiled16<BLOCK>), dim3(p.n16), dim3(BLOCK), lds, s, h.rows, h.cols, p.n16, h.d_row_ptr,
-                       p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, p.d_list16);
+                       p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, p.d_list16, p.region);
     return check_launch("k_tiled16");
 }
 
