@@ -638,6 +638,17 @@ __global__ void k_carry_fixup(int nchunks, int chunk, const int32_t *__restrict_
     y[r] = s;
 }
 
+// plan: how many rows continue past their owner chunk (0 -> the fix-up launch is skipped)
+__global__ void k_plan_spans(int nchunks, int chunk, const int32_t *__restrict__ row_ptr,
+                             const int32_t *__restrict__ chunk_lb, int32_t *__restrict__ count)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks - 1) return;
+    const int lb0 = chunk_lb[c], lb1 = chunk_lb[c + 1];
+    if (lb1 == lb0) return;
+    if ((int64_t)row_ptr[lb1] > (int64_t)(c + 1) * chunk) atomicAdd(count, 1);
+}
+
 // ---------------------------------------------------------------------------
 static int check_launch(const char *what)
 {
@@ -683,6 +694,20 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
                        h.d_row_ptr, p.d_lb);
     int rc = check_launch("k_plan_chunks");
     if (rc) return rc;
+    {
+        DevPtr<int32_t> cnt;
+        SPMV_HIP_TRY(cnt.alloc(1));
+        SPMV_HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int32_t), s));
+        if (p.nchunks > 1) {
+            hipLaunchKernelGGL(k_plan_spans, dim3((p.nchunks - 1 + 255) / 256), dim3(256), 0, s, p.nchunks, chunk,
+                               h.d_row_ptr, p.d_lb, cnt.p);
+            if ((rc = check_launch("k_plan_spans"))) return rc;
+        }
+        int32_t spans = 0;
+        SPMV_HIP_TRY(hipMemcpyAsync(&spans, cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SPMV_HIP_TRY(hipStreamSynchronize(s));
+        p.spanning_rows = spans;
+    }
     if (windows) {
         // [2*nchunks] windows + 2 words of statistics
         SPMV_HIP_TRY(hipMalloc((void **)&p.d_win, sizeof(int32_t) * (2 * (size_t)p.nchunks + 2)));
@@ -933,7 +958,7 @@ int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hip
     else if (p.block == 512) rc = launch_either<512, true>(persist, h, p, x, y, s);
     else rc = launch_either<1024, true>(persist, h, p, x, y, s);
     if (rc) return rc;
-    if (p.nchunks > 1) {
+    if (p.nchunks > 1 && p.spanning_rows > 0) {  // chunk boundaries that all fall on row boundaries need no fix-up
         hipLaunchKernelGGL(k_carry_fixup, dim3((p.nchunks - 1 + 255) / 256), dim3(256), 0, s, p.nchunks,
                            chunk_of(p.block), h.d_row_ptr, p.d_lb, p.d_carry, y);
         rc = check_launch("k_carry_fixup");

@@ -59,6 +59,7 @@ struct ChunkPlan {
     int32_t *d_list32 = nullptr;   // [nchunks - n16] the others, run by k_adaptive
     int n16 = 0;
     int maxpass = 0;
+    int spanning_rows = 0;         // rows that continue past their owner chunk (0: no fix-up launch)
     int region = 0;                // floats of the dynamic LDS region (x slice, then products)
     bool persist = false;      // persistent software-pipelined launch (measured slower: DESIGN.md section 4)
     int staged_single = 0;     // TILED: chunks whose whole column span is staged in one pass
