@@ -829,37 +829,51 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
     hipEvent_t e0, e1;
     SPMV_HIP_TRY(hipEventCreate(&e0));
     SPMV_HIP_TRY(hipEventCreate(&e1));
-    ChunkPlan best;
+    bool have = false;
     float best_ms = 0.0f;
+    int best_block = 0, best_pass = 0, best_narrow = 0, best_single = 0, best_chunks = 0;
     int rc = SPMV_OK;
     for (const Cand &c : cands) {
         ChunkPlan &p = h.plan_tiled;
         int single = 0, full = 0;
         if ((rc = build_plan(h, c.block, c.maxpass, s, p, &single, &full))) break;
-        if (p.nchunks == 0) { best = p; p = ChunkPlan(); break; }
-        if ((rc = build_col16(h, p, s))) break;  // time what will actually run
-        if ((rc = launch_adaptive(h, xt.p, yt.p, true, s))) break;  // warm (code object, attribute)
-        hipEventRecord(e0, s);
-        for (int i = 0; i < 3 && rc == SPMV_OK; ++i) rc = launch_adaptive(h, xt.p, yt.p, true, s);
-        hipEventRecord(e1, s);
-        if (rc || hipEventSynchronize(e1) != hipSuccess) { rc = rc ? rc : SPMV_ERR_HIP; break; }
-        float ms = 0.0f;
-        hipEventElapsedTime(&ms, e0, e1);
-        if (!best.block || ms < best_ms) {
-            free_plan(best);
-            best = p;
-            best_ms = ms;
-            p = ChunkPlan();  // ownership moved to `best`
+        if (p.nchunks == 0) break;
+        // time the candidate with 32-bit columns, then with the 16-bit copy: the copy usually wins
+        // (6 instead of 8 bytes per nonzero) but costs a second launch over the chunks without it,
+        // which can lose on power-law rows
+        for (int narrow = 0; narrow < 2 && rc == SPMV_OK; ++narrow) {
+            if (narrow) {
+                if ((rc = build_col16(h, p, s))) break;
+                if (!p.d_col16) break;  // nothing eligible: same configuration as just timed
+            }
+            if ((rc = launch_adaptive(h, xt.p, yt.p, true, s))) break;  // warm (code object, attribute)
+            hipEventRecord(e0, s);
+            for (int i = 0; i < 3 && rc == SPMV_OK; ++i) rc = launch_adaptive(h, xt.p, yt.p, true, s);
+            hipEventRecord(e1, s);
+            if (rc || hipEventSynchronize(e1) != hipSuccess) { rc = rc ? rc : SPMV_ERR_HIP; break; }
+            float ms = 0.0f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (!have || ms < best_ms) {
+                have = true;
+                best_ms = ms;
+                best_block = c.block;
+                best_pass = c.maxpass;
+                best_narrow = narrow;
+                best_single = single;
+                best_chunks = p.nchunks;
+            }
         }
+        if (rc) break;
         // every chunk already staged in one pass: larger workgroups only add barrier cost
-        if (single == best.nchunks && best.block == c.block) break;
+        if (best_single == best_chunks && best_block == c.block) break;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    free_plan(h.plan_tiled);
-    if (rc) { free_plan(best); return rc; }
-    h.plan_tiled = best;
-    return SPMV_OK;
+    if (rc) { free_plan(h.plan_tiled); return rc; }
+    if (!have) return SPMV_OK;  // no nonzeros: the (empty) plan built last stands
+    // rebuild the winner (plans are cheap next to the trials)
+    if ((rc = build_plan(h, best_block, best_pass, s, h.plan_tiled, nullptr, nullptr))) return rc;
+    return best_narrow ? build_col16(h, h.plan_tiled, s) : SPMV_OK;
 }
 
 void destroy_plans(spmv_csr &h)
