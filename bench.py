@@ -264,6 +264,17 @@ def main():
                                "kind": "port",
                                "sample": f"rows [{s0},{s1}) of the same matrix ({n} rows, {k1 - k0} nnz, full x), "
                                          f"{reps} passes, {t_cpu:.1f} s, oracle_spmv_csr_mt"}
+        # the reference's own CPU path as it runs it: the dense SgemvCPU loop (tester.cpp:36-45), one thread,
+        # 4096 x 4096 at 50 % zeros (test/main.cpp:4, tester.cpp:106) -- restated in oracle/, timed here
+        Ad, xd = W.dense_random(4096, 4096, 0.5, seed=1)
+        orc.sgemv_dense(Ad, xd)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            orc.sgemv_dense(Ad, xd)
+        dense_ms = (time.perf_counter() - t1) / 3 * 1e3
+        out["cpu_baseline"]["reference_dense_loop"] = {
+            "what": "SgemvCPU restated (oracle_sgemv_dense), 4096x4096, 50 % zeros, 1 thread",
+            "ms": round(dense_ms, 2), "dense_GBs": round(4096 * 4096 * 4 / dense_ms / 1e6, 2)}
         # parity on the sample while both results are at hand (the oracle as checker)
         y64, mag = orc.spmv_f64(rps, ci, va, x)
         got = d_y[s0:s1].cpu().numpy().astype(np.float64)

@@ -171,3 +171,21 @@ def test_shard_rebases_to_int32_and_refuses_overflow(pkg):
     assert list(s2) == [0, 10]
     with pytest.raises(ValueError):
         P.shard_row_ptr(rp, 0, 4)
+
+
+@pytest.mark.skipif(not Path("/root/reference/src/include/kernel.hpp").exists(), reason="/root/reference not present")
+def test_launcher_prototypes_match_the_reference_header():
+    """Every prototype of the reference's kernel.hpp:8-17 appears in include/kernel.hpp with the same
+    name and parameter list (the drop-in is symbol-for-symbol)."""
+    def protos(text):
+        out = {}
+        for m in re.finditer(r"^void\s+(\w+_gemv_gpu)\s*\(([^)]*)\)\s*;", text, flags=re.M):
+            params = [re.sub(r"\s+", " ", p.strip()) for p in m.group(2).split(",")]
+            out[m.group(1)] = [re.sub(r"\s*\w+$", "", p).replace(" *", "*").strip() for p in params]   # types only
+        return out
+    ref = protos(Path("/root/reference/src/include/kernel.hpp").read_text())
+    ours = protos((ROOT / "include" / "kernel.hpp").read_text())
+    assert len(ref) == 10
+    for name, types in ref.items():
+        assert name in ours, name
+        assert ours[name] == types, (name, ours[name], types)
