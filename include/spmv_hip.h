@@ -143,7 +143,9 @@ SPMV_API int spmv_csr_run_host(spmv_csr_t *h, int variant, const float *x_host, 
  * y[i] = sum_j x[j] * A[j*N+i] on the dense device matrix.
  * replaces: cublas_gemv_gpu (cublas.cu:4-44), naive_kernel (naive.cu:4-11),
  * tiling_kernel (tiling_smem.cu:4-32).  mode 0 = thread per output (naive),
- * 1 = LDS-staged x tile (tiling), 2 = split-M wave-coalesced (vendor slot). */
+ * 1 = LDS-staged x tile (tiling), 2 = split-M wave-coalesced (vendor slot),
+ * 3 = mode 2 + activation sparsity: rows of A whose x[j] is 0 are not read
+ *     (asp_kernel_v0/1/2, src/kernels/asp.cu:20-26). */
 SPMV_API int spmv_dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode,
                     void *stream);
 

@@ -195,6 +195,11 @@ __global__ __launch_bounds__(kBlock) void k_gemv_xtile(int M, int N, const float
 
 // mode 2: rows of A split into kSlabs slabs -> N/256 x kSlabs workgroups stream A with
 // coalesced 256-B-per-wave rows; per-slab partials are combined in slab order.
+// mode 3 (SKIP): the same with the reference's activation-sparsity idea (asp_kernel_v*,
+// /root/reference/src/kernels/asp.cu:20-26: "if x_i != 0 load A and FMA"): x[j] is the same for every
+// lane, so the test is wave-uniform and a zero x[j] skips the 1-KiB row segment of A entirely --
+// with the tester's 50 %-zero x (tester.cpp:154) half of A is never read.
+template <bool SKIP>
 __global__ __launch_bounds__(kBlock) void k_gemv_split(int M, int N, const float *__restrict__ A,
                                                        const float *__restrict__ x, float *__restrict__ part)
 {
@@ -206,12 +211,16 @@ __global__ __launch_bounds__(kBlock) void k_gemv_split(int M, int N, const float
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
     int j = j0;
     for (; j + 3 < j1; j += 4) {
-        a0 = fmaf(x[j], A[(size_t)j * N + i], a0);
-        a1 = fmaf(x[j + 1], A[(size_t)(j + 1) * N + i], a1);
-        a2 = fmaf(x[j + 2], A[(size_t)(j + 2) * N + i], a2);
-        a3 = fmaf(x[j + 3], A[(size_t)(j + 3) * N + i], a3);
+        const float x0 = x[j], x1 = x[j + 1], x2 = x[j + 2], x3 = x[j + 3];
+        if (!SKIP || x0 != 0.0f) a0 = fmaf(x0, A[(size_t)j * N + i], a0);
+        if (!SKIP || x1 != 0.0f) a1 = fmaf(x1, A[(size_t)(j + 1) * N + i], a1);
+        if (!SKIP || x2 != 0.0f) a2 = fmaf(x2, A[(size_t)(j + 2) * N + i], a2);
+        if (!SKIP || x3 != 0.0f) a3 = fmaf(x3, A[(size_t)(j + 3) * N + i], a3);
     }
-    for (; j < j1; ++j) a0 = fmaf(x[j], A[(size_t)j * N + i], a0);
+    for (; j < j1; ++j) {
+        const float xj = x[j];
+        if (!SKIP || xj != 0.0f) a0 = fmaf(xj, A[(size_t)j * N + i], a0);
+    }
     part[(size_t)s * N + i] = (a0 + a1) + (a2 + a3);
 }
 
@@ -237,10 +246,13 @@ int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int
         hipLaunchKernelGGL(k_gemv_xtile, dim3(blocks), dim3(kBlock), 0, s, M, N, d_A, d_x, d_y);
         return check_launch("k_gemv_xtile");
     }
-    if (mode == 2) {
+    if (mode == 2 || mode == 3) {
         float *d_part = nullptr;
         SPMV_HIP_TRY(hipMallocAsync((void **)&d_part, sizeof(float) * (size_t)kSlabs * N, s));
-        hipLaunchKernelGGL(k_gemv_split, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, d_part);
+        if (mode == 3)
+            hipLaunchKernelGGL(k_gemv_split<true>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, d_part);
+        else
+            hipLaunchKernelGGL(k_gemv_split<false>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, d_part);
         if ((rc = check_launch("k_gemv_split"))) return rc;
         hipLaunchKernelGGL(k_gemv_combine, dim3(blocks), dim3(kBlock), 0, s, N, d_part, d_y);
         if ((rc = check_launch("k_gemv_combine"))) return rc;

@@ -69,7 +69,7 @@ def test_run_host_path(pkg, oracle, gpu):
     assert_close_to_oracle(y2, y64, mag, "run_host/adaptive")
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_dense_gemv_slots(pkg, oracle, gpu, mode):
     import torch
     g = load_golden("g256x384_10pct")
