@@ -18,6 +18,8 @@
 //           set bits of its own bitmap word (see k_tcsr_spmv).  No decompression, no barrier.
 #include "spmv_internal.hpp"
 
+using f4 = float __attribute__((ext_vector_type(4)));
+
 struct spmv_tcsr {
     int M = 0, N = 0;
     int64_t nnz = 0, nblocks = 0;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_tcsr_spmv(int M, int N, int nseg, co
                                                       const float *__restrict__ vals, const float *__restrict__ x,
                                                       float *__restrict__ partial)
 {
-    __shared__ float vals_s[kTcsrWaves][2][1024];
+    __shared__ __attribute__((aligned(16))) float vals_s[kTcsrWaves][2][1024 + 16];
     __shared__ float xs[kTcsrWaves][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, i = lane & 31;
@@ -118,16 +120,21 @@ __global__ __launch_bounds__(kBlock) void k_tcsr_spmv(int M, int N, int nseg, co
         const uint32_t word = live ? bitmaps[b * 32 + i] : 0u;
         const int base = blk_idx[b];
         const int cnt = live ? blk_idx[b + 1] - base : 0;
-        // the block's values: 32 predicated loads per lane issued back to back (a block holds at
-        // most 1024), then parked in LDS -- a load-then-store loop would expose one HBM round trip
-        // per 32 values
-        float r[32];
+        // the block's values (contiguous, <= 1024 floats, start anywhere): 16-byte loads from the
+        // 16-byte-aligned address below `base`, parked in LDS at the same alignment -- up to eight
+        // loads per lane, all issued before the first store (a load-then-store loop would expose
+        // one HBM round trip per iteration); value k of the block then sits at vs[shift + k]
+        const int shift = base & 3;
+        const int nvec = (shift + cnt + 3) >> 2;  // <= 257: the 9th trip covers a block of 1021..1024 values starting at shift 1..3
+        f4 r[9];
+        const f4 *v4 = reinterpret_cast<const f4 *>(vals + (base - shift));
 #pragma unroll
-        for (int q = 0; q < 32; ++q) r[q] = (i + 32 * q < cnt) ? vals[base + i + 32 * q] : 0.0f;
+        for (int q = 0; q < 9; ++q)
+            if (i + 32 * q < nvec) r[q] = v4[i + 32 * q];
         if (half == 0) xw[i] = x[by * 32 + i];
 #pragma unroll
-        for (int q = 0; q < 32; ++q)
-            if (i + 32 * q < cnt) vs[i + 32 * q] = r[q];
+        for (int q = 0; q < 9; ++q)
+            if (i + 32 * q < nvec) *reinterpret_cast<f4 *>(vs + 4 * (i + 32 * q)) = r[q];
         // exclusive prefix of the per-column counts inside the half
         int inc = __popc(word);
 #pragma unroll
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_tcsr_spmv(int M, int N, int nseg, co
             int v = __shfl_up(inc, o, 32);
             if (i >= o) inc += v;
         }
-        int off = inc - __popc(word);
+        int off = shift + inc - __popc(word);
         if (DENSE) {
             // all 32 bit positions, predicated: fixed trip count, 32 independent LDS reads in flight
 #pragma unroll
@@ -195,7 +202,7 @@ int tcsr_from_dense(int M, int N, const float *d_A, hipStream_t s, spmv_tcsr_t *
         if ((rc = check_launch("k_tcsr_sentinel"))) return rc;
         SPMV_HIP_TRY(hipMemcpyAsync(&nnz, total.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         SPMV_HIP_TRY(hipStreamSynchronize(s));
-        SPMV_HIP_TRY(vals.alloc((size_t)nnz));
+        SPMV_HIP_TRY(vals.alloc((size_t)nnz + 4));  // k_tcsr_spmv reads whole 16-byte vectors around a block
         if (nnz > 0) {
             hipLaunchKernelGGL(k_tcsr_fill, dim3(grid), dim3(kBlock), 0, s, M, N, d_A, bitmaps.p, blk_idx.p, vals.p);
             if ((rc = check_launch("k_tcsr_fill"))) return rc;
