@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""tools/vendor_compare.py -- rocSPARSE csrmv beside this library, same matrices, same process.
+
+SURVEY.md section 8 a-9: the vendor library is the COMPARISON slot at configs 2-4 (the reference's
+own vendor slot is cublasSgemv, cublas.cu:33, on the dense matrix).  Nothing here is on the product
+path: rocSPARSE (/opt/rocm/lib/librocsparse.so, part of the ROCm image) is loaded with ctypes, its
+four CSR SpMV algorithms are preprocessed and timed with HIP events, their y is checked against
+ours, and one JSON line per (workload, implementation) is printed.
+
+    python tools/vendor_compare.py [--out FILE] [--iters 30]
+"""
+import argparse
+import ctypes
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as ge  # noqa: E402
+
+ALGS = {"csr_adaptive": 2, "csr_rowsplit": 3, "csr_lrb": 7, "csr_nnzsplit": 8}
+STAGE_SIZE, STAGE_PREP, STAGE_COMPUTE = 1, 2, 3
+I32, F32 = 2, 151          # rocsparse_indextype_i32, rocsparse_datatype_f32_r; 111 below = rocsparse_operation_none
+
+WORKLOADS = [
+    ("c2", dict(rows=1 << 20, dist="const", mean=16, band=0)),
+    ("c2", dict(rows=1 << 20, dist="const", mean=16, band=8192)),
+    ("c3", dict(rows=4 << 20, dist="powerlaw", mean=32, band=0)),
+    ("c3", dict(rows=4 << 20, dist="powerlaw", mean=32, band=8192)),
+    ("c4", dict(rows=16 << 20, dist="mixed", mean=16, band=0)),
+    ("c4", dict(rows=16 << 20, dist="mixed", mean=16, band=8192)),
+]
+
+
+class RocSparse:
+    def __init__(self):
+        L = ctypes.CDLL("/opt/rocm/lib/librocsparse.so")
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        L.rocsparse_create_handle.argtypes = [ctypes.POINTER(vp)]
+        L.rocsparse_set_stream.argtypes = [vp, vp]
+        L.rocsparse_create_csr_descr.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, vp, i32, i32, i32, i32]
+        L.rocsparse_create_dnvec_descr.argtypes = [ctypes.POINTER(vp), i64, vp, i32]
+        L.rocsparse_spmv.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_size_t), vp]
+        L.rocsparse_destroy_spmat_descr.argtypes = [vp]
+        L.rocsparse_destroy_dnvec_descr.argtypes = [vp]
+        L.rocsparse_destroy_handle.argtypes = [vp]
+        self.L = L
+        self.h = vp()
+        self._ok(L.rocsparse_create_handle(ctypes.byref(self.h)), "create_handle")
+
+    @staticmethod
+    def _ok(st, what):
+        if st != 0:
+            raise RuntimeError(f"rocsparse {what}: status {st}")
+
+    def close(self):
+        self.L.rocsparse_destroy_handle(self.h)
+
+
+def main():
+    import numpy as np
+    import torch
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="")
+    ap.add_argument("--iters", type=int, default=30)
+    args = ap.parse_args()
+
+    pkg = ge.load_package()
+    capi, W = pkg.capi, pkg.workloads
+    dev = torch.device("cuda:0")
+    rs = RocSparse()
+    stream = torch.cuda.current_stream().cuda_stream
+    rs._ok(rs.L.rocsparse_set_stream(rs.h, ctypes.c_void_p(stream)), "set_stream")
+    one = ctypes.c_float(1.0)
+    zero = ctypes.c_float(0.0)
+    lines = []
+
+    def emit(**kw):
+        lines.append(kw)
+        print(json.dumps(kw), flush=True)
+
+    for cname, spec in WORKLOADS:
+        torch.cuda.empty_cache()
+        w = W.Workload(cname, spec["rows"], spec["rows"], spec["dist"], spec["mean"], band=spec["band"])
+        rp = W.row_ptr(w)
+        d_rp = torch.from_numpy(rp).to(dev)
+        d_ci = torch.empty(w.nnz, dtype=torch.int32, device=dev)
+        d_va = torch.empty(w.nnz, dtype=torch.float32, device=dev)
+        d_x = torch.empty(w.cols, dtype=torch.float32, device=dev)
+        d_y = torch.empty(w.rows, dtype=torch.float32, device=dev)
+        d_yv = torch.empty(w.rows, dtype=torch.float32, device=dev)
+        capi.synth_fill(w.seed, 0, w.rows, w.rows, w.cols, w.band, d_rp, d_ci, d_va)
+        capi.synth_x(w.seed, 0, w.cols, d_x)
+        B = W.algorithmic_bytes(w.rows, w.cols, w.nnz)
+        label = f"{cname} band {w.band}" if w.band else f"{cname} uniform"
+
+        A = capi.CsrMatrix.from_device(w.rows, w.cols, d_rp, d_ci, d_va)
+        ours = {}
+        for vname in ("scalar", "wave", "adaptive", "tiled"):
+            v = capi.VARIANTS[vname]
+            A.plan(v)
+            A.time(v, d_x, d_y, 3)
+            ms = min(A.time(v, d_x, d_y, args.iters) for _ in range(3))
+            ours[vname] = ms
+            emit(workload=label, impl=f"this:{vname}", ms=round(ms, 4), GBs=round(B / ms / 1e6, 1),
+                 pct_of_8TBs=round(B / ms / 1e6 / 80, 2))
+        A.run(capi.TILED, d_x, d_y)
+        torch.cuda.synchronize()
+        y_ours = d_y.clone()
+
+        vx, vy = ctypes.c_void_p(), ctypes.c_void_p()
+        rs._ok(rs.L.rocsparse_create_dnvec_descr(ctypes.byref(vx), w.cols, d_x.data_ptr(), F32), "dnvec x")
+        rs._ok(rs.L.rocsparse_create_dnvec_descr(ctypes.byref(vy), w.rows, d_yv.data_ptr(), F32), "dnvec y")
+        for aname, alg in ALGS.items():
+            size = ctypes.c_size_t(0)
+            # the analysis of an algorithm is cached INSIDE the matrix descriptor: a fresh one per algorithm
+            mat = ctypes.c_void_p()
+            rs._ok(rs.L.rocsparse_create_csr_descr(ctypes.byref(mat), w.rows, w.cols, w.nnz, d_rp.data_ptr(),
+                                                   d_ci.data_ptr(), d_va.data_ptr(), I32, I32, 0, F32), "create_csr")
+
+            def call(stage, buf, mat=mat, alg=alg, size=size):
+                return rs.L.rocsparse_spmv(rs.h, 111, ctypes.byref(one), mat, vx, ctypes.byref(zero), vy, F32, alg,
+                                           stage, ctypes.byref(size), buf)
+            st = call(STAGE_SIZE, None)
+            if st != 0:
+                emit(workload=label, impl=f"rocsparse:{aname}", error=f"buffer_size status {st}")
+                continue
+            buf = torch.empty(max(int(size.value), 16), dtype=torch.uint8, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            st = call(STAGE_PREP, buf.data_ptr())
+            e1.record()
+            torch.cuda.synchronize()
+            if st != 0:
+                emit(workload=label, impl=f"rocsparse:{aname}", error=f"preprocess status {st}")
+                continue
+            prep_ms = e0.elapsed_time(e1)
+            d_yv.zero_()      # (NaN-prefilled y comes back NaN from some rocSPARSE algorithms even with beta = 0)
+            for _ in range(3):
+                st = call(STAGE_COMPUTE, buf.data_ptr())
+            if st != 0:
+                emit(workload=label, impl=f"rocsparse:{aname}", error=f"compute status {st}")
+                continue
+            best = float("inf")
+            for _ in range(3):
+                e0.record()
+                for _ in range(args.iters):
+                    call(STAGE_COMPUTE, buf.data_ptr())
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / args.iters)
+            diff = (d_yv - y_ours).abs().max().item()
+            emit(workload=label, impl=f"rocsparse:{aname}", ms=round(best, 4), GBs=round(B / best / 1e6, 1),
+                 pct_of_8TBs=round(B / best / 1e6 / 80, 2), preprocess_ms=round(prep_ms, 3),
+                 workspace_bytes=int(size.value), max_abs_diff_vs_this=diff,
+                 this_tiled_speedup=round(best / ours["tiled"], 2))
+            del buf
+            torch.cuda.synchronize()
+            rs.L.rocsparse_destroy_spmat_descr(mat)
+        rs.L.rocsparse_destroy_dnvec_descr(vx)
+        rs.L.rocsparse_destroy_dnvec_descr(vy)
+        A.close()
+    rs.close()
+    if args.out:
+        Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(args.out).write_text("\n".join(json.dumps(l) for l in lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
