@@ -97,6 +97,13 @@ SPMV_API int spmv_csr_from_dense_device(int M, int N, const float *d_A, void *st
 /* Copy the handle's CSR arrays back (row_ptr: rows+1 entries).  Any pointer may be NULL. */
 SPMV_API int spmv_csr_download(const spmv_csr_t *h, int32_t *row_ptr, int32_t *col_idx, float *vals);
 
+/* Check the arrays on the device: row_ptr[0] == 0, row_ptr non-decreasing, row_ptr[rows] == nnz, every column
+ * index in [0, cols).  SPMV_ERR_INVALID + spmv_last_error() names the first offending row / element.  Both
+ * spmv_csr_create_* call it (one pass over row_ptr and col_idx, synchronous): the kernels index x and their LDS
+ * windows with these numbers unchecked, so a malformed matrix must never reach them.  The reference has no
+ * counterpart (its CSR only ever comes from its own dense scan, matrix_csr.cpp:5-23). */
+SPMV_API int spmv_csr_validate(const spmv_csr_t *h, void *stream);
+
 SPMV_API int spmv_csr_dims(const spmv_csr_t *h, int64_t *rows, int64_t *cols, int64_t *nnz);
 SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
 

@@ -35,6 +35,7 @@ SIGNATURES = {
     "spmv_csr_from_dense_host": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
     "spmv_csr_from_dense_device": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
     "spmv_csr_download": (C.c_int, [_H, _i32p, _i32p, _f32p]),
+    "spmv_csr_validate": (C.c_int, [_H, C.c_void_p]),
     "spmv_csr_dims": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "spmv_csr_destroy": (C.c_int, [_H]),
     "spmv_csr_plan": (C.c_int, [_H, C.c_int, _vp]),

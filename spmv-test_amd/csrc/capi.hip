@@ -1,5 +1,6 @@
 // capi.hip -- the extern "C" entry points of include/spmv_hip.h.
 #include <cstdarg>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include "spmv_internal.hpp"
@@ -78,6 +79,35 @@ static int check_dims(int64_t rows, int64_t cols, int64_t nnz)
     return SPMV_OK;
 }
 
+int spmv_csr_validate(const spmv_csr_t *h, void *stream)
+{
+    if (!h) { set_error("spmv_csr_validate: null handle"); return SPMV_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t init[4] = {INT32_MAX, INT32_MAX, 0, (int32_t)h->nnz};
+    int32_t bad[4];
+    DevPtr<int32_t> d_bad;
+    SPMV_HIP_TRY(d_bad.alloc(4));
+    SPMV_HIP_TRY(hipMemcpyAsync(d_bad.p, init, sizeof init, hipMemcpyHostToDevice, st));
+    int rc = launch_validate(h, d_bad.p, st);
+    if (rc) return rc;
+    SPMV_HIP_TRY(hipMemcpyAsync(bad, d_bad.p, sizeof bad, hipMemcpyDeviceToHost, st));
+    SPMV_HIP_TRY(hipStreamSynchronize(st));
+    if (bad[2] != 0 || (int64_t)bad[3] != h->nnz) {
+        set_error("malformed CSR: row_ptr[0]=%d row_ptr[rows]=%d, expected 0 and nnz=%lld", bad[2], bad[3],
+                  (long long)h->nnz);
+        return SPMV_ERR_INVALID;
+    }
+    if (bad[0] != INT32_MAX) {
+        set_error("malformed CSR: row_ptr decreases or leaves [0, nnz] at row %d", bad[0]);
+        return SPMV_ERR_INVALID;
+    }
+    if (bad[1] != INT32_MAX) {
+        set_error("malformed CSR: column index of element %d is outside [0, %lld)", bad[1], (long long)h->cols);
+        return SPMV_ERR_INVALID;
+    }
+    return SPMV_OK;
+}
+
 int spmv_csr_create_host(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
                          const int32_t *col_idx, const float *vals, spmv_csr_t **out)
 {
@@ -109,6 +139,10 @@ int spmv_csr_create_host(int64_t rows, int64_t cols, int64_t nnz, const int32_t 
     h->owns_arrays = true;
     if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
     h->d_row_ptr = rp.release(); h->d_col_idx = ci.release(); h->d_vals = va.release();
+    if ((rc = spmv_csr_validate(h, nullptr))) {
+        spmv_csr_destroy(h);
+        return rc;
+    }
     *out = h;
     return SPMV_OK;
 }
@@ -132,7 +166,11 @@ int spmv_csr_create_device(int64_t rows, int64_t cols, int64_t nnz, const int32_
     h->rows = rows; h->cols = cols; h->nnz = nnz;
     h->d_row_ptr = d_row_ptr; h->d_col_idx = d_col_idx; h->d_vals = d_vals;
     h->owns_arrays = false;
-    SPMV_HIP_TRY(hipGetDevice(&h->device));
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+    if ((rc = spmv_csr_validate(h, nullptr))) {
+        delete h;
+        return rc;
+    }
     *out = h;
     return SPMV_OK;
 }

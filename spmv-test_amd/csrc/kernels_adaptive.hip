@@ -847,12 +847,12 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
                 if (!p.d_col16) break;  // nothing eligible: same configuration as just timed
             }
             if ((rc = launch_adaptive(h, xt.p, yt.p, true, s))) break;  // warm (code object, attribute)
-            hipEventRecord(e0, s);
+            bool timed = hipEventRecord(e0, s) == hipSuccess;
             for (int i = 0; i < 3 && rc == SPMV_OK; ++i) rc = launch_adaptive(h, xt.p, yt.p, true, s);
-            hipEventRecord(e1, s);
-            if (rc || hipEventSynchronize(e1) != hipSuccess) { rc = rc ? rc : SPMV_ERR_HIP; break; }
+            timed = timed && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
             float ms = 0.0f;
-            hipEventElapsedTime(&ms, e0, e1);
+            timed = timed && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (rc || !timed) { rc = rc ? rc : SPMV_ERR_HIP; break; }
             if (!have || ms < best_ms) {
                 have = true;
                 best_ms = ms;

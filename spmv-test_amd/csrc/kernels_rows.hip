@@ -201,4 +201,39 @@ int launch_vector(const spmv_csr &h, const float *x, float *y, hipStream_t s)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Structural validation (spmv_csr_validate): grid-stride over rows and elements, first offender by atomicMin.
+__global__ __launch_bounds__(256) void k_validate(int64_t rows, int64_t cols, int64_t nnz,
+                                                  const int32_t *__restrict__ row_ptr,
+                                                  const int32_t *__restrict__ col_idx, int32_t *__restrict__ bad)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t r = t; r < rows; r += stride) {
+        const int32_t a = row_ptr[r], b = row_ptr[r + 1];
+        if (a > b || a < 0 || (int64_t)b > nnz) atomicMin(&bad[0], (int32_t)r);
+    }
+    for (int64_t k = t; k < nnz; k += stride) {
+        const int32_t c = col_idx[k];
+        if (c < 0 || (int64_t)c >= cols) atomicMin(&bad[1], (int32_t)k);
+    }
+    if (t == 0) {
+        if (row_ptr[0] != 0) bad[2] = row_ptr[0];
+        if ((int64_t)row_ptr[rows] != nnz) bad[3] = row_ptr[rows];
+    }
+}
+
+int launch_validate(const spmv_csr *h, int32_t *d_bad4, hipStream_t stream)
+{
+    const int64_t work = h->nnz > h->rows ? h->nnz : h->rows;
+    int64_t blocks = (work + 256 * 8 - 1) / (256 * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    k_validate<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(h->rows, h->cols, h->nnz, h->d_row_ptr,
+                                                                   h->d_col_idx, d_bad4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_validate launch", __FILE__, __LINE__);
+    return SPMV_OK;
+}
+
 }  // namespace spmv

@@ -101,6 +101,9 @@ int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out
 int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s);
 
 // in-place exclusive scan of n int32 (one 1024-thread workgroup); the total goes to *d_total
+// kernels_rows.hip: structural check of a CSR (bad[0] first row with row_ptr[r] > row_ptr[r+1] or outside [0,nnz],
+// bad[1] first element with a column outside [0,cols), bad[2]/bad[3] row_ptr[0] / row_ptr[rows] when wrong)
+int launch_validate(const spmv_csr *h, int32_t *d_bad4, hipStream_t stream);
 int exclusive_scan_i32(int32_t *d_data, int64_t n, int32_t *d_total, hipStream_t s);
 
 int tcsr_from_dense(int M, int N, const float *d_A, hipStream_t s, spmv_tcsr_t **out);

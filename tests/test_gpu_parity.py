@@ -158,6 +158,35 @@ def test_error_conventions(pkg, gpu):
     assert e.value.status == capi.ERR_INVALID
 
 
+def test_malformed_csr_is_refused_before_any_kernel_sees_it(pkg, gpu):
+    """spmv_csr_validate (called by both create entry points): the kernels index x and LDS with these numbers."""
+    import torch
+    capi = pkg.capi
+    va = np.ones(4, np.float32)
+    cases = {
+        "column index of element 2": (np.array([0, 2, 4], np.int32), np.array([0, 1, 7, 1], np.int32)),    # col >= cols
+        "column index of element 0": (np.array([0, 2, 4], np.int32), np.array([-1, 1, 0, 1], np.int32)),   # negative
+        "row_ptr decreases or leaves [0, nnz] at row 1": (np.array([0, 3, 2, 4], np.int32), np.array([0, 1, 0, 1], np.int32)),
+    }
+    for needle, (rp, ci) in cases.items():
+        rows = len(rp) - 1
+        with pytest.raises(capi.SpmvError) as e:
+            capi.CsrMatrix.from_host(rows, 2, rp, ci, va)
+        assert e.value.status == capi.ERR_INVALID and needle in str(e.value), str(e.value)
+        d_rp, d_ci, d_va = (torch.from_numpy(a).to(gpu) for a in (rp, ci, va))
+        with pytest.raises(capi.SpmvError) as e:
+            capi.CsrMatrix.from_device(rows, 2, d_rp, d_ci, d_va)
+        assert e.value.status == capi.ERR_INVALID and needle in str(e.value), str(e.value)
+    # a well-formed one with unsorted and duplicate columns is accepted (the kernels do not need sorted rows)
+    rp, ci = np.array([0, 2, 4], np.int32), np.array([1, 0, 1, 1], np.int32)
+    A = capi.CsrMatrix.from_host(2, 2, rp, ci, va)
+    x = torch.tensor([1.0, 10.0], device=gpu); y = torch.zeros(2, device=gpu)
+    for v in capi.VARIANTS.values():
+        A.plan(v); A.run(v, x, y)
+        torch.cuda.synchronize()
+        assert y.tolist() == [11.0, 20.0]
+
+
 def test_results_are_deterministic_run_to_run(pkg, oracle, gpu):
     w = pkg.workloads.config("c3", scale=1 / 32)
     prob = synth_problem(pkg, oracle, gpu, w)
