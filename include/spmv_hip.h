@@ -66,7 +66,14 @@ enum spmv_variant {
     SPMV_TILED = 5,     /* ADAPTIVE + the chunk's window of x staged in LDS:       */
                         /*   csr_tiling_kernel     src/kernels/csr_tiling.cu:24-114,*/
                         /*   wsp_sm_kernel         src/kernels/wsp_sm.cu:6-211     */
-    SPMV_VARIANT_COUNT = 6
+    SPMV_PANEL = 6,     /* (row block x column panel) sweep for columns without       */
+                        /* locality: a wavefront keeps its block's sums in LDS and all */
+                        /* resident waves walk the panels of x in step, so the panel   */
+                        /* stays in L2.  The sparse-scale counterpart of the reference's*/
+                        /* tiled format: TCSRMatrix src/tcsr.cpp:5-38 + csr_tiling_kernel*/
+                        /* src/kernels/csr_tiling.cu:24-114.  Its plan COPIES the values */
+                        /* (re-plan after changing them).                               */
+    SPMV_VARIANT_COUNT = 7
 };
 
 /* ---- runtime ---------------------------------------------------------- */

@@ -15,9 +15,9 @@ LAUNCHERS_PATH = PKG_DIR / "lib" / "libspmv_launchers.so"
 TESTER_PATH = PKG_DIR / "bin" / "sparse_sgemv"
 
 # enum spmv_variant
-SCALAR, WAVE, WAVE_PIPE, VECTOR, ADAPTIVE, TILED = range(6)
+SCALAR, WAVE, WAVE_PIPE, VECTOR, ADAPTIVE, TILED, PANEL = range(7)
 VARIANTS = {"scalar": SCALAR, "wave": WAVE, "wave_pipe": WAVE_PIPE, "vector": VECTOR,
-            "adaptive": ADAPTIVE, "tiled": TILED}
+            "adaptive": ADAPTIVE, "tiled": TILED, "panel": PANEL}
 
 # enum spmv_status
 OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_VARIANT, ERR_NOT_PLANNED = 0, -1, -2, -3, -4, -5

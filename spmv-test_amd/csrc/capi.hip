@@ -65,6 +65,7 @@ const char *spmv_variant_name(int variant)
         case SPMV_VECTOR: return "vector";
         case SPMV_ADAPTIVE: return "adaptive";
         case SPMV_TILED: return "tiled";
+        case SPMV_PANEL: return "panel";
         default: return "unknown";
     }
 }
@@ -251,6 +252,7 @@ int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream)
         case SPMV_VECTOR: return plan_vector(*h, s);
         case SPMV_ADAPTIVE: return plan_adaptive(*h, false, s);
         case SPMV_TILED: return plan_adaptive(*h, true, s);
+        case SPMV_PANEL: return plan_panel(*h, s);
         default:
             set_error("spmv_csr_plan: unknown variant %d", variant);
             return SPMV_ERR_VARIANT;
@@ -275,6 +277,7 @@ int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void 
         case SPMV_VECTOR: return launch_vector(*h, d_x, d_y, s);
         case SPMV_ADAPTIVE: return launch_adaptive(*h, d_x, d_y, false, s);
         case SPMV_TILED: return launch_adaptive(*h, d_x, d_y, true, s);
+        case SPMV_PANEL: return launch_panel(*h, d_x, d_y, s);
         default:
             set_error("spmv_csr_run: unknown variant %d", variant);
             return SPMV_ERR_VARIANT;
@@ -292,6 +295,8 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
                    (h->plan_tiled.d_col16 ? (int64_t)h->plan_tiled.nchunks * 4 +
                                                 (int64_t)h->plan_tiled.n16 * 2 * h->plan_tiled.block * kNnzPerThread
                                           : 0);
+        case SPMV_PANEL:     // tile_ptr; packed/pvals REPLACE col_idx/vals byte for byte
+            return (int64_t)h->plan_panel.nblocks * (h->plan_panel.npanels + 1) * 4 + ((int64_t)h->plan_panel.nblocks + 1) * 4;
         default: return 0;
     }
 }
@@ -301,6 +306,10 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
     if (!h || !buf || n <= 0) { set_error("spmv_csr_plan_describe: bad argument"); return SPMV_ERR_INVALID; }
     const ChunkPlan *p = variant == SPMV_ADAPTIVE ? &h->plan_adaptive : (variant == SPMV_TILED ? &h->plan_tiled : nullptr);
     if (variant == SPMV_VECTOR) snprintf(buf, (size_t)n, "lanes_per_row=%d", h->vector_width);
+    else if (variant == SPMV_PANEL && h->plan_panel.ready)
+        snprintf(buf, (size_t)n, "panel_columns=%d panels=%d row_blocks=%d waves_per_launch=%d launches=%d",
+                 1 << h->plan_panel.pw_bits, h->plan_panel.npanels, h->plan_panel.nblocks,
+                 h->plan_panel.waves_per_launch, panel_launches(h->plan_panel));
     else if (!p) snprintf(buf, (size_t)n, "no plan");
     else if (!p->block) snprintf(buf, (size_t)n, "not planned");
     else

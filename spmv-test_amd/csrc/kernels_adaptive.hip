@@ -880,6 +880,7 @@ void destroy_plans(spmv_csr &h)
 {
     free_plan(h.plan_adaptive);
     free_plan(h.plan_tiled);
+    destroy_panel(h.plan_panel);
 }
 
 static int resident_workgroups(int block, int waves_simd)

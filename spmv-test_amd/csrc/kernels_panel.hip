@@ -1,0 +1,483 @@
+// kernels_panel.hip -- SPMV_PANEL: a (row block x column panel) sweep for matrices whose columns have no locality.
+//
+// Why: with columns drawn from all of a large x (tens of MiB), every CSR kernel of this library -- and every
+// rocSPARSE algorithm -- pays one L2-missing fabric request per nonzero (~56 G/s on MI355X).
+// Here the rows are cut into blocks of equal NONZERO count (at most 9728 rows; as many blocks as fill every
+// resident wave slot), and the nonzeros of a block are re-ordered, once, by COLUMN PANEL (2^pw_bits columns,
+// 512 KiB of x by default).  One wavefront owns the block: its output sums live in LDS for the whole sweep, it
+// streams its re-ordered nonzeros front to back, and because every wave of the launch walks the panels in the
+// same order at the same pace (equal loads), the slice of x they are all
+// gathering from stays in each XCD's 4 MiB L2.  The grid of one launch is exactly what is resident on the chip (a
+// second launch takes the next set of row blocks): a wave that starts late is out of step with the others, and the
+// L2 then holds several panels instead of one (measured with tools/ubench_panel.hip: 2.3 ms instead of 1.2 ms on
+// the 16Mi x 16Mi / 2^28-nonzero uniform workload).  Low occupancy is deliberate for the same reason -- 4 waves per
+// CU, each with 2 x 16 sixteen-byte loads in flight, beat 16 or 32 waves per CU.
+//
+// The reference's tiled format (TCSRMatrix, src/tcsr.cpp:5-38, multiplied by csr_tiling_kernel,
+// src/kernels/csr_tiling.cu:24-114: 32 x 32 tiles, x tile and tile values in shared memory) is the same idea at
+// dense-matrix scale; this is its sparse-matrix, cache-sized counterpart.
+//
+// Layout (PanelPlan): for row block b (rows [brow[b], brow[b+1])) the nonzeros keep their CSR range
+// [row_ptr[brow[b]], row_ptr[brow[b+1]]) but are stably sorted by panel:
+//   packed[k] = row_in_block << 18 | join << 17 | column_in_panel     pvals[k] = value   (8 B per nonzero, as CSR)
+//   (join: the nonzero 4 places earlier in the same tile has the same row -- the two would meet in one instruction)
+//   tile_ptr[b*(np+1) + p] = first k of panel p in block b (tile_ptr[..+np] = end of the block)
+// Inside a tile rows ascend, so the lanes of one instruction normally hold distinct rows and the sum into LDS is a
+// plain read-add-write (an LDS float atomic per nonzero costs more than the whole rest of the kernel: measured);
+// the plan marks the nonzeros whose left neighbour in an instruction holds the same row; a group of four
+// instructions that holds such a mark, or straddles two tiles, adds with LDS atomics instead.  No barriers; a wave's
+// sums are touched by that wave alone, in instruction order.
+// The values are COPIED at plan time (the other variants read the live vals array): re-plan after changing them.
+#include <climits>
+#include "spmv_internal.hpp"
+
+namespace spmv {
+
+namespace {
+
+constexpr int kRwTarget = 8192;            // rows per wave block the launch count is sized for
+constexpr int kRw = 9728;                  // most rows of one block (equal-nonzero cuts vary): 38 KiB of LDS per wave
+constexpr int kColBits = 17;               // column_in_panel field of packed[]
+constexpr unsigned kColMask = (1u << kColBits) - 1;
+constexpr unsigned kJoinBit = 1u << kColBits;   // this nonzero and the one 4 places before it in its tile share a row
+constexpr int kRowShift = kColBits + 1;
+constexpr int kWavesPerWg = 2;             // 76 KiB of LDS per workgroup -> 2 workgroups = 4 waves per CU
+constexpr int kVec = 4;                    // 16-byte vectors per lane per step and per array
+constexpr int kStep = kWave * 4 * kVec;    // 1024 nonzeros per wave per step
+constexpr int kMaxPanels = 4096;
+
+using u4 = unsigned __attribute__((ext_vector_type(4)));
+using f4 = float __attribute__((ext_vector_type(4)));
+
+// ---- plan kernels -----------------------------------------------------------------------------------------
+// Row blocks with equal NONZERO counts (waves that carry equal loads stay in step): cut[b] = first row whose
+// row_ptr reaches b * nnz / nb.
+__global__ void k_panel_cuts(int64_t rows, int64_t nnz, int nb, const int32_t *__restrict__ row_ptr,
+                             int32_t *__restrict__ cut)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    if (b == nb) {
+        cut[b] = (int32_t)rows;
+        return;
+    }
+    const int64_t target = nnz * b / nb;
+    int64_t lo = 0, hi = rows;   // first r in [0, rows] with row_ptr[r] >= target
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)row_ptr[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    cut[b] = (int32_t)lo;
+}
+// a cut of more than kRw rows (a stretch of short or empty rows) is split evenly: nsub[b] pieces
+__global__ void k_panel_nsub(int nb, const int32_t *__restrict__ cut, int32_t *__restrict__ nsub)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb) nsub[b] = (cut[b + 1] - cut[b] + kRw - 1) / kRw;
+}
+__global__ void k_panel_brow(int64_t rows, int nb, const int32_t *__restrict__ cut, const int32_t *__restrict__ off,
+                             const int32_t *__restrict__ total, int32_t *__restrict__ brow)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) brow[*total] = (int32_t)rows;
+    if (b >= nb) return;
+    const int len = cut[b + 1] - cut[b];
+    const int n = (len + kRw - 1) / kRw;
+    if (n == 0) return;
+    const int step = (len + n - 1) / n;
+    for (int i = 0; i < n; ++i) brow[off[b] + i] = cut[b] + i * step;
+}
+
+// tile_ptr of one row block: histogram of the panels of its nonzeros, then an exclusive scan.
+__global__ __launch_bounds__(256) void k_panel_tiles(const int32_t *__restrict__ brow,
+                                                     const int32_t *__restrict__ row_ptr,
+                                                     const int32_t *__restrict__ col_idx, int pw_bits, int np,
+                                                     int32_t *__restrict__ tile_ptr)
+{
+    __shared__ int hist[kMaxPanels];
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    const int s = row_ptr[brow[blockIdx.x]], e = row_ptr[brow[blockIdx.x + 1]];
+    for (int p = tid; p < np; p += 256) hist[p] = 0;
+    __syncthreads();
+    for (int k = s + tid; k < e; k += 256) atomicAdd(&hist[col_idx[k] >> pw_bits], 1);
+    __syncthreads();
+    // thread t scans entries [t*per, (t+1)*per)
+    const int per = (np + 255) / 256;
+    int sum = 0;
+    for (int i = 0; i < per; ++i) {
+        const int p = tid * per + i;
+        if (p < np) sum += hist[p];
+    }
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = s + part[tid] - sum;
+    int32_t *tp = tile_ptr + (int64_t)blockIdx.x * (np + 1);
+    for (int i = 0; i < per; ++i) {
+        const int p = tid * per + i;
+        if (p < np) {
+            tp[p] = run;
+            run += hist[p];
+        }
+    }
+    if (tid == 0) tp[np] = e;
+}
+
+// row_in_block of every nonzero (temporary, 2 B per nonzero): one workgroup per row block, one lane per row,
+// long rows by the whole wave.
+__global__ __launch_bounds__(256) void k_panel_rowloc(const int32_t *__restrict__ brow,
+                                                      const int32_t *__restrict__ row_ptr,
+                                                      uint16_t *__restrict__ rowloc)
+{
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int row0 = brow[blockIdx.x], row1 = brow[blockIdx.x + 1];
+    for (int r0 = row0 + w * kWave; r0 < row1; r0 += 4 * kWave) {
+        const int r = r0 + lane;
+        int a = 0, b = 0;
+        if (r < row1) {
+            a = row_ptr[r];
+            b = row_ptr[r + 1];
+        }
+        const uint16_t mine = (uint16_t)(r - row0);
+        const bool is_long = b - a > 64;
+        if (!is_long)
+            for (int k = a; k < b; ++k) rowloc[k] = mine;
+        unsigned long long todo = __ballot(is_long);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int la = __shfl(a, src), lb = __shfl(b, src);
+            const uint16_t lr = (uint16_t)__shfl((int)mine, src);
+            for (int k = la + lane; k < lb; k += kWave) rowloc[k] = lr;
+        }
+    }
+}
+
+// Stable scatter of one row block into panel order: one wave per block, 64 nonzeros per step in CSR order; the
+// rank of a nonzero among the same-panel nonzeros of its step comes from a ballot per distinct panel.
+__global__ __launch_bounds__(256) void k_panel_fill(int nblocks, const int32_t *__restrict__ brow,
+                                                    const int32_t *__restrict__ row_ptr,
+                                                    const int32_t *__restrict__ col_idx,
+                                                    const float *__restrict__ vals,
+                                                    const uint16_t *__restrict__ rowloc, int pw_bits, int np,
+                                                    const int32_t *__restrict__ tile_ptr,
+                                                    uint32_t *__restrict__ packed, float *__restrict__ pvals)
+{
+    __shared__ int cursor_all[4][kMaxPanels];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int wb = blockIdx.x * 4 + w;
+    if (wb >= nblocks) return;
+    int *cursor = cursor_all[w];
+    const int32_t *tp = tile_ptr + (int64_t)wb * (np + 1);
+    for (int p = lane; p < np; p += kWave) cursor[p] = tp[p];
+    const int s = row_ptr[brow[wb]], e = row_ptr[brow[wb + 1]];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned cmask = (1u << pw_bits) - 1u;
+    for (int base = s; base < e; base += kWave) {
+        const int k = base + lane;
+        const bool valid = k < e;
+        int col = 0, rl = 0;
+        float v = 0.0f;
+        if (valid) {
+            col = col_idx[k];
+            rl = rowloc[k];
+            v = vals[k];
+        }
+        const int p = col >> pw_bits;
+        int dest = 0;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int pl = __shfl(p, leader);
+            const unsigned long long m = __ballot(valid && p == pl);
+            const int first = cursor[pl];
+            if (valid && p == pl) dest = first + __popcll(m & lt);
+            if (lane == leader) cursor[pl] = first + __popcll(m);
+            todo &= ~m;
+        }
+        if (valid) {
+            packed[dest] = ((unsigned)rl << kRowShift) | ((unsigned)col & cmask);
+            pvals[dest] = v;
+        }
+    }
+}
+
+// join bits: nonzero k and nonzero k-4 of the SAME tile have the same row.  Lanes of one multiply instruction hold
+// stream positions 4 apart, so an instruction without join bits (and inside one tile) holds 64 distinct rows.
+__global__ __launch_bounds__(256) void k_panel_joins(const int32_t *__restrict__ brow, int np,
+                                                     const int32_t *__restrict__ row_ptr,
+                                                     const int32_t *__restrict__ tile_ptr, uint32_t *__restrict__ packed)
+{
+    const int s = row_ptr[brow[blockIdx.x]], e = row_ptr[brow[blockIdx.x + 1]];
+    const int32_t *tp = tile_ptr + (int64_t)blockIdx.x * (np + 1);
+    for (int k = s + 4 + (int)threadIdx.x; k < e; k += 256) {
+        int lo = 0, hi = np;                     // tile of k: the last p with tp[p] <= k
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (tp[mid] <= k) lo = mid; else hi = mid;
+        }
+        if (k - 4 >= tp[lo] && (packed[k - 4] >> kRowShift) == (packed[k] >> kRowShift)) atomicOr(&packed[k], kJoinBit);
+    }
+}
+
+// ---- the multiply -------------------------------------------------------------------------------------------
+struct StepRegs {
+    u4 c[kVec];
+    f4 v[kVec];
+};
+
+__device__ __forceinline__ void panel_load(const u4 *__restrict__ c4, const f4 *__restrict__ v4, int base, int lane,
+                                           StepRegs &r)
+{
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+        const int i = (base >> 2) + j * kWave + lane;
+        r.c[j] = __builtin_nontemporal_load(&c4[i]);
+        r.v[j] = __builtin_nontemporal_load(&v4[i]);
+    }
+}
+
+__global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, const int32_t *__restrict__ brow,
+                                                              const int32_t *__restrict__ row_ptr,
+                                                              const int32_t *__restrict__ tile_ptr,
+                                                              const uint32_t *__restrict__ packed,
+                                                              const float *__restrict__ pvals,
+                                                              const float *__restrict__ x, float *__restrict__ y,
+                                                              int np, int pw_bits)
+{
+    __shared__ float ys_all[kWavesPerWg][kRw];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int wb = wb0 + blockIdx.x * kWavesPerWg + w;
+    if (wb >= wb1) return;   // no barrier anywhere below: the waves of a workgroup are independent
+    float *ys = ys_all[w];
+    const int row0 = brow[wb], row1 = brow[wb + 1];
+    const int n = row1 - row0;
+    for (int i = lane; i < n; i += kWave) ys[i] = 0.0f;
+    const int s = row_ptr[row0], e = row_ptr[row1];
+    const int32_t *tp = tile_ptr + (int64_t)wb * (np + 1);
+    const u4 *c4 = reinterpret_cast<const u4 *>(packed);
+    const f4 *v4 = reinterpret_cast<const f4 *>(pvals);
+    const int k0 = s & ~3;
+    const int nsteps = (e - k0 + kStep - 1) / kStep;
+    int pdone = 0;   // boundaries tp[1..pdone] lie at or before the current step
+
+    auto work = [&](int base, const StepRegs &r) {
+        // panel of every element: pdone + the boundaries inside this step that lie at or before it
+        int pv[kVec][4];
+#pragma unroll
+        for (int j = 0; j < kVec; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pv[j][q] = pdone;
+        int p = pdone + 1;
+        while (p < np) {
+            const int bnd = tp[__builtin_amdgcn_readfirstlane(p)];
+            if ((int64_t)bnd >= (int64_t)base + kStep) break;
+#pragma unroll
+            for (int j = 0; j < kVec; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pv[j][q] += (base + (j * kWave + lane) * 4 + q >= bnd) ? 1 : 0;
+            ++p;
+        }
+        pdone = p - 1;
+        const bool interior = base >= s && (int64_t)base + kStep <= (int64_t)e;
+        float xv[kVec][4];
+#pragma unroll
+        for (int j = 0; j < kVec; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = base + (j * kWave + lane) * 4 + q;
+                const bool ok = interior || (k >= s && k < e);
+                const int64_t col = ((int64_t)pv[j][q] << pw_bits) | (int64_t)(r.c[j][q] & kColMask);
+                xv[j][q] = ok ? x[col] : 0.0f;
+            }
+#pragma unroll
+        for (int j = 0; j < kVec; ++j) {
+            // the four instructions of group j cover 256 consecutive stream positions: one tile, no join bits,
+            // all valid -> 64 distinct rows each, plain read-add-write
+            const unsigned joins = (r.c[j][0] | r.c[j][1] | r.c[j][2] | r.c[j][3]) & kJoinBit;
+            const bool simple = interior &&
+                                __builtin_amdgcn_readlane(pv[j][0], 0) == __builtin_amdgcn_readlane(pv[j][3], 63) &&
+                                __ballot(joins != 0u) == 0ull;
+            if (simple) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = (int)(r.c[j][q] >> kRowShift);
+                    ys[row] = ys[row] + r.v[j][q] * xv[j][q];
+                }
+            } else {
+                // a tile boundary, a repeated row or the ragged end of the stream: LDS atomics (one wave, in
+                // instruction order).  Cheaper than sorting the cases out lane by lane -- measured, DESIGN.md.
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = base + (j * kWave + lane) * 4 + q;
+                    const bool ok = interior || (k >= s && k < e);
+                    if (ok) atomicAdd(&ys[(int)(r.c[j][q] >> kRowShift)], r.v[j][q] * xv[j][q]);
+                }
+            }
+        }
+    };
+
+    StepRegs ra, rb;
+    if (nsteps > 0) panel_load(c4, v4, k0, lane, ra);
+    for (int st = 0; st < nsteps; st += 2) {
+        const int base = k0 + st * kStep;
+        if (st + 1 < nsteps) panel_load(c4, v4, base + kStep, lane, rb);
+        work(base, ra);
+        if (st + 2 < nsteps) panel_load(c4, v4, base + 2 * kStep, lane, ra);
+        if (st + 1 < nsteps) work(base + kStep, rb);
+    }
+    for (int i = lane; i < n; i += kWave) y[row0 + i] = ys[i];
+}
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, what, __FILE__, __LINE__);
+    return SPMV_OK;
+}
+
+}  // namespace
+
+void destroy_panel(PanelPlan &p)
+{
+    if (p.d_packed) (void)hipFree(p.d_packed);
+    if (p.d_pvals) (void)hipFree(p.d_pvals);
+    if (p.d_tile_ptr) (void)hipFree(p.d_tile_ptr);
+    if (p.d_brow) (void)hipFree(p.d_brow);
+    p = PanelPlan();
+}
+
+// one launch = one set of co-resident waves sweeping in step: 2 workgroups (4 waves) per CU
+static int resident_waves()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    return cus * 2 * kWavesPerWg;
+}
+
+int plan_panel(spmv_csr &h, hipStream_t s)
+{
+    destroy_panel(h.plan_panel);
+    PanelPlan p;
+    if (h.nnz > (int64_t)INT_MAX - 4 * kStep) {
+        set_error("spmv_csr_plan(panel): nnz %lld too close to 2^31 for one handle", (long long)h.nnz);
+        return SPMV_ERR_INVALID;
+    }
+    int bits = kColBits;   // 128Ki columns = 512 KiB of x per panel
+    if (const char *e = getenv("SPMV_PANEL_BITS")) bits = atoi(e);
+    if (bits < 8) bits = 8;
+    if (bits > kColBits) bits = kColBits;
+    while (bits < kColBits && ((h.cols + (1ll << bits) - 1) >> bits) > kMaxPanels) ++bits;
+    p.pw_bits = bits;
+    p.npanels = (int)((h.cols + (1ll << bits) - 1) >> bits);
+    if (p.npanels < 1) p.npanels = 1;
+    if (p.npanels > kMaxPanels) {
+        set_error("spmv_csr_plan(panel): %lld columns need more than %d panels of 2^%d columns", (long long)h.cols,
+                  kMaxPanels, kColBits);
+        return SPMV_ERR_INVALID;
+    }
+    // row blocks: equal nonzero counts, as many as fill the resident wave slots of every launch
+    p.waves_per_launch = resident_waves();
+    if (const char *e = getenv("SPMV_PANEL_WAVES")) {
+        const int v = atoi(e);
+        if (v > 0) p.waves_per_launch = v;
+    }
+    if (h.rows == 0) {
+        p.ready = true;
+        h.plan_panel = p;
+        return SPMV_OK;
+    }
+    const int64_t launches0 =
+        (h.rows + (int64_t)p.waves_per_launch * kRwTarget - 1) / ((int64_t)p.waves_per_launch * kRwTarget);
+    int64_t nb0 = launches0 * p.waves_per_launch;
+    if (nb0 > h.rows) nb0 = h.rows;
+    DevPtr<int32_t> cut, nsub, total, brow;
+    SPMV_HIP_TRY(cut.alloc((size_t)nb0 + 1));
+    SPMV_HIP_TRY(nsub.alloc((size_t)nb0));
+    SPMV_HIP_TRY(total.alloc(1));
+    const unsigned gb = (unsigned)((nb0 + 1 + 255) / 256);
+    k_panel_cuts<<<dim3(gb), dim3(256), 0, s>>>(h.rows, h.nnz, (int)nb0, h.d_row_ptr, cut.p);
+    int rc = check_launch("k_panel_cuts");
+    if (rc) return rc;
+    k_panel_nsub<<<dim3(gb), dim3(256), 0, s>>>((int)nb0, cut.p, nsub.p);
+    if ((rc = check_launch("k_panel_nsub"))) return rc;
+    if ((rc = exclusive_scan_i32(nsub.p, nb0, total.p, s))) return rc;
+    int32_t nblocks = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&nblocks, total.p, sizeof nblocks, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    p.nblocks = nblocks;
+    SPMV_HIP_TRY(brow.alloc((size_t)p.nblocks + 1));
+    k_panel_brow<<<dim3(gb), dim3(256), 0, s>>>(h.rows, (int)nb0, cut.p, nsub.p, total.p, brow.p);
+    if ((rc = check_launch("k_panel_brow"))) return rc;
+
+    DevPtr<uint32_t> packed;
+    DevPtr<float> pvals;
+    DevPtr<int32_t> tiles;
+    DevPtr<uint16_t> rowloc;
+    const size_t slots = (size_t)h.nnz + 2 * kStep + 8;   // the last step of a block reads past its end
+    SPMV_HIP_TRY(packed.alloc(slots));
+    SPMV_HIP_TRY(pvals.alloc(slots));
+    SPMV_HIP_TRY(tiles.alloc((size_t)p.nblocks * (size_t)(p.npanels + 1)));
+    SPMV_HIP_TRY(rowloc.alloc((size_t)h.nnz));
+    SPMV_HIP_TRY(hipMemsetAsync(packed.p + h.nnz, 0, sizeof(uint32_t) * (slots - (size_t)h.nnz), s));
+    SPMV_HIP_TRY(hipMemsetAsync(pvals.p + h.nnz, 0, sizeof(float) * (slots - (size_t)h.nnz), s));
+    k_panel_tiles<<<dim3((unsigned)p.nblocks), dim3(256), 0, s>>>(brow.p, h.d_row_ptr, h.d_col_idx, p.pw_bits,
+                                                                   p.npanels, tiles.p);
+    if ((rc = check_launch("k_panel_tiles"))) return rc;
+    if (h.nnz > 0) {
+        k_panel_rowloc<<<dim3((unsigned)p.nblocks), dim3(256), 0, s>>>(brow.p, h.d_row_ptr, rowloc.p);
+        if ((rc = check_launch("k_panel_rowloc"))) return rc;
+        k_panel_fill<<<dim3((unsigned)((p.nblocks + 3) / 4)), dim3(256), 0, s>>>(
+            p.nblocks, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, p.pw_bits, p.npanels, tiles.p, packed.p,
+            pvals.p);
+        if ((rc = check_launch("k_panel_fill"))) return rc;
+        k_panel_joins<<<dim3((unsigned)p.nblocks), dim3(256), 0, s>>>(brow.p, p.npanels, h.d_row_ptr, tiles.p,
+                                                                       packed.p);
+        if ((rc = check_launch("k_panel_joins"))) return rc;
+    }
+    SPMV_HIP_TRY(hipStreamSynchronize(s));   // the temporaries are freed on return
+    p.d_packed = packed.release();
+    p.d_pvals = pvals.release();
+    p.d_tile_ptr = tiles.release();
+    p.d_brow = brow.release();
+    p.ready = true;
+    h.plan_panel = p;
+    return SPMV_OK;
+}
+
+int panel_launches(const PanelPlan &p)
+{
+    return p.nblocks && p.waves_per_launch ? (p.nblocks + p.waves_per_launch - 1) / p.waves_per_launch : 0;
+}
+
+int launch_panel(const spmv_csr &h, const float *x, float *y, hipStream_t s)
+{
+    const PanelPlan &p = h.plan_panel;
+    if (!p.ready) {
+        set_error("spmv_csr_run: variant panel is not planned (call spmv_csr_plan first)");
+        return SPMV_ERR_NOT_PLANNED;
+    }
+    // equal shares: 1536 blocks on 1024 slots run as 768 + 768, not 1024 + 512
+    const int launches = panel_launches(p);
+    if (launches == 0) return SPMV_OK;   // no rows
+    const int share = (p.nblocks + launches - 1) / launches;
+    for (int b0 = 0; b0 < p.nblocks; b0 += share) {
+        const int b1 = b0 + share < p.nblocks ? b0 + share : p.nblocks;
+        const int g = (b1 - b0 + kWavesPerWg - 1) / kWavesPerWg;
+        k_panel<<<dim3((unsigned)g), dim3(kWave * kWavesPerWg), 0, s>>>(b0, b1, p.d_brow, h.d_row_ptr, p.d_tile_ptr,
+                                                                        p.d_packed, p.d_pvals, x, y, p.npanels, p.pw_bits);
+        const int rc = check_launch("k_panel");
+        if (rc) return rc;
+    }
+    return SPMV_OK;
+}
+
+}  // namespace spmv

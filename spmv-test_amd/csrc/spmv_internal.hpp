@@ -66,6 +66,19 @@ struct ChunkPlan {
     int staged_full = 0;       // TILED: chunks staged completely (any number of passes)
 };
 
+// SPMV_PANEL (kernels_panel.hip): row blocks of at most 8192 rows and equal nonzero counts, each block's nonzeros stably sorted by column panel.
+struct PanelPlan {
+    bool ready = false;
+    int pw_bits = 0;               // log2(columns per panel)
+    int npanels = 0;
+    int nblocks = 0;               // row blocks (<= 8192 rows, equal nonzero counts) = wavefronts of work
+    int waves_per_launch = 0;      // what is resident at once: one launch = one sweep in step
+    uint32_t *d_packed = nullptr;  // [nnz + slack] row_in_block << 19 | column_in_panel
+    float *d_pvals = nullptr;      // [nnz + slack] values in the same order (a COPY: re-plan after changing vals)
+    int32_t *d_tile_ptr = nullptr; // [nblocks * (npanels + 1)]
+    int32_t *d_brow = nullptr;     // [nblocks + 1] first row of every block
+};
+
 }  // namespace spmv
 
 struct spmv_tcsr;  // kernels_tcsr.hip
@@ -83,6 +96,7 @@ struct spmv_csr {
     int vector_width = 0;          // SPMV_VECTOR: lanes per row (2..32), 0 = not planned
     spmv::ChunkPlan plan_adaptive; // SPMV_ADAPTIVE: 256-thread workgroups
     spmv::ChunkPlan plan_tiled;    // SPMV_TILED: workgroup size chosen from the column windows
+    spmv::PanelPlan plan_panel;    // SPMV_PANEL
 };
 
 namespace spmv {
@@ -92,7 +106,11 @@ int launch_scalar(const spmv_csr &h, const float *x, float *y, hipStream_t s);
 int launch_wave(const spmv_csr &h, const float *x, float *y, bool pipelined, hipStream_t s);
 int launch_vector(const spmv_csr &h, const float *x, float *y, hipStream_t s);
 int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s);
+int launch_panel(const spmv_csr &h, const float *x, float *y, hipStream_t s);
 
+int plan_panel(spmv_csr &h, hipStream_t s);
+void destroy_panel(PanelPlan &p);
+int panel_launches(const PanelPlan &p);
 int plan_vector(spmv_csr &h, hipStream_t s);
 int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s);
 void destroy_plans(spmv_csr &h);
@@ -100,10 +118,10 @@ void destroy_plans(spmv_csr &h);
 int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out);
 int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s);
 
-// in-place exclusive scan of n int32 (one 1024-thread workgroup); the total goes to *d_total
 // kernels_rows.hip: structural check of a CSR (bad[0] first row with row_ptr[r] > row_ptr[r+1] or outside [0,nnz],
 // bad[1] first element with a column outside [0,cols), bad[2]/bad[3] row_ptr[0] / row_ptr[rows] when wrong)
 int launch_validate(const spmv_csr *h, int32_t *d_bad4, hipStream_t stream);
+// in-place exclusive scan of n int32 (one 1024-thread workgroup); the total goes to *d_total
 int exclusive_scan_i32(int32_t *d_data, int64_t n, int32_t *d_total, hipStream_t s);
 
 int tcsr_from_dense(int M, int N, const float *d_A, hipStream_t s, spmv_tcsr_t **out);

@@ -49,6 +49,43 @@ def test_tiled_plan_picks_workgroup_size_from_the_data(pkg, oracle, gpu):
         assert_close_to_oracle(y, y64, mag, f"band {band}")
 
 
+
+@pytest.mark.parametrize("bits,wgs", [("8", "2"), ("11", "6"), ("17", "")])
+def test_panel_variant_small_panels_many_launches(pkg, oracle, gpu, monkeypatch, bits, wgs):
+    """SPMV_PANEL with 256-column panels (thousands of tiles, instructions that straddle tiles, empty tiles),
+    one workgroup per launch (every launch boundary), and the shipped geometry; giant rows take the run-sum
+    path (>= 5 nonzeros of one row in one tile).  Results are reproducible bit for bit."""
+    monkeypatch.setenv("SPMV_PANEL_BITS", bits)
+    if wgs:
+        monkeypatch.setenv("SPMV_PANEL_WAVES", wgs)
+    W = pkg.workloads
+    cases = [W.config("c3", scale=1 / 32), W.config("c4", scale=1 / 64), W.config("c4", band=4096, scale=1 / 64),
+             W.Workload("tall", 3 * W.BLOCK_ROWS, 3 * W.BLOCK_ROWS, "const", 16, band=0)]
+    for w in cases:
+        prob = synth_problem(pkg, oracle, gpu, w)
+        y = prob.run(pkg.capi.PANEL)
+        y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+        assert not np.isnan(y).any(), w.name
+        assert_close_to_oracle(y, y64, mag, f"panel bits={bits} wgs={wgs or 'resident'} {w.name}")
+        assert "panels=" in prob.A.plan_describe(pkg.capi.PANEL)
+        assert np.array_equal(prob.run(pkg.capi.PANEL).view(np.uint32), y.view(np.uint32))
+        prob.A.close()
+
+
+def test_panel_plan_copies_the_values(pkg, oracle, gpu):
+    """include/spmv_hip.h: the PANEL plan re-orders and COPIES vals; the other variants read them live."""
+    import torch
+    w = pkg.workloads.config("c4", scale=1 / 64)
+    prob = synth_problem(pkg, oracle, gpu, w)
+    y0 = prob.run(pkg.capi.PANEL)
+    prob.d_va.mul_(2.0)
+    prob.A.run(pkg.capi.PANEL, prob.d_x, prob.d_y)
+    torch.cuda.synchronize()
+    assert np.array_equal(prob.d_y[:w.rows].cpu().numpy(), y0)                 # still the planned values
+    y1 = prob.run(pkg.capi.PANEL)                                              # run() plans again
+    assert np.array_equal(y1, 2.0 * y0)
+    assert np.array_equal(prob.run(pkg.capi.TILED).view(np.uint32), prob.run(pkg.capi.TILED).view(np.uint32))
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

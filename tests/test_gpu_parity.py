@@ -13,7 +13,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-VARIANT_NAMES = ["scalar", "wave", "wave_pipe", "vector", "adaptive", "tiled"]
+VARIANT_NAMES = ["scalar", "wave", "wave_pipe", "vector", "adaptive", "tiled", "panel"]
 
 
 def _check_all_variants(pkg, oracle, prob, what):
