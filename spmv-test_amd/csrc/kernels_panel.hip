@@ -227,9 +227,16 @@ __global__ __launch_bounds__(256) void k_panel_joins(const int32_t *__restrict__
 }
 
 // ---- the multiply -------------------------------------------------------------------------------------------
-struct StepRegs {
+struct StepRegs {     // one step of the stream, as loaded
     u4 c[kVec];
     f4 v[kVec];
+};
+struct GatherRegs {   // one step between its gathers and its sums
+    float xv[kVec][4];
+    float val[kVec][4];
+    int row[kVec][4];
+    bool simple[kVec];
+    bool interior;
 };
 
 __device__ __forceinline__ void panel_load(const u4 *__restrict__ c4, const f4 *__restrict__ v4, int base, int lane,
@@ -267,7 +274,12 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
     const int nsteps = (e - k0 + kStep - 1) / kStep;
     int pdone = 0;   // boundaries tp[1..pdone] lie at or before the current step
 
-    auto work = [&](int base, const StepRegs &r) {
+    // Two stages per step, one step apart, so that a step's 16 gathers per lane are in flight while the previous
+    // step is being summed (one wave per SIMD: nothing else hides their latency).
+    //   gather(step): panel of every element, issue the x loads, keep what the sums need (the stream registers are
+    //                 free for the next load right after);
+    //   sum(step):    add into the wave's LDS sums.
+    auto gather = [&](int base, const StepRegs &r, GatherRegs &g) {
         // panel of every element: pdone + the boundaries inside this step that lie at or before it
         int pv[kVec][4];
 #pragma unroll
@@ -285,52 +297,67 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
             ++p;
         }
         pdone = p - 1;
-        const bool interior = base >= s && (int64_t)base + kStep <= (int64_t)e;
-        float xv[kVec][4];
-#pragma unroll
-        for (int j = 0; j < kVec; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = base + (j * kWave + lane) * 4 + q;
-                const bool ok = interior || (k >= s && k < e);
-                const int64_t col = ((int64_t)pv[j][q] << pw_bits) | (int64_t)(r.c[j][q] & kColMask);
-                xv[j][q] = ok ? x[col] : 0.0f;
-            }
+        g.interior = base >= s && (int64_t)base + kStep <= (int64_t)e;
 #pragma unroll
         for (int j = 0; j < kVec; ++j) {
             // the four instructions of group j cover 256 consecutive stream positions: one tile, no join bits,
-            // all valid -> 64 distinct rows each, plain read-add-write
+            // all valid -> 64 distinct rows each
             const unsigned joins = (r.c[j][0] | r.c[j][1] | r.c[j][2] | r.c[j][3]) & kJoinBit;
-            const bool simple = interior &&
-                                __builtin_amdgcn_readlane(pv[j][0], 0) == __builtin_amdgcn_readlane(pv[j][3], 63) &&
-                                __ballot(joins != 0u) == 0ull;
-            if (simple) {
+            g.simple[j] = g.interior &&
+                          __builtin_amdgcn_readlane(pv[j][0], 0) == __builtin_amdgcn_readlane(pv[j][3], 63) &&
+                          __ballot(joins != 0u) == 0ull;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = (int)(r.c[j][q] >> kRowShift);
-                    ys[row] = ys[row] + r.v[j][q] * xv[j][q];
+            for (int q = 0; q < 4; ++q) {
+                const int64_t col = ((int64_t)pv[j][q] << pw_bits) | (int64_t)(r.c[j][q] & kColMask);
+                if (g.interior) {
+                    g.xv[j][q] = x[col];
+                } else {
+                    const int k = base + (j * kWave + lane) * 4 + q;
+                    g.xv[j][q] = (k >= s && k < e) ? x[col] : 0.0f;
                 }
+                g.row[j][q] = (int)(r.c[j][q] >> kRowShift);
+                g.val[j][q] = r.v[j][q];
+            }
+        }
+    };
+    auto sum = [&](int base, const GatherRegs &g) {
+#pragma unroll
+        for (int j = 0; j < kVec; ++j) {
+            if (g.simple[j]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ys[g.row[j][q]] = ys[g.row[j][q]] + g.val[j][q] * g.xv[j][q];
             } else {
                 // a tile boundary, a repeated row or the ragged end of the stream: LDS atomics (one wave, in
                 // instruction order).  Cheaper than sorting the cases out lane by lane -- measured, DESIGN.md.
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int k = base + (j * kWave + lane) * 4 + q;
-                    const bool ok = interior || (k >= s && k < e);
-                    if (ok) atomicAdd(&ys[(int)(r.c[j][q] >> kRowShift)], r.v[j][q] * xv[j][q]);
+                    if (g.interior || (k >= s && k < e)) atomicAdd(&ys[g.row[j][q]], g.val[j][q] * g.xv[j][q]);
                 }
             }
         }
     };
 
-    StepRegs ra, rb;
-    if (nsteps > 0) panel_load(c4, v4, k0, lane, ra);
+    StepRegs s0, s1;
+    GatherRegs g0, g1;
+    auto step_base = [&](int st) { return k0 + st * kStep; };
+    if (nsteps > 0) {
+        panel_load(c4, v4, step_base(0), lane, s0);
+        if (nsteps > 1) panel_load(c4, v4, step_base(1), lane, s1);
+        gather(step_base(0), s0, g0);
+        if (nsteps > 2) panel_load(c4, v4, step_base(2), lane, s0);
+    }
     for (int st = 0; st < nsteps; st += 2) {
-        const int base = k0 + st * kStep;
-        if (st + 1 < nsteps) panel_load(c4, v4, base + kStep, lane, rb);
-        work(base, ra);
-        if (st + 2 < nsteps) panel_load(c4, v4, base + 2 * kStep, lane, ra);
-        if (st + 1 < nsteps) work(base + kStep, rb);
+        if (st + 1 < nsteps) {
+            gather(step_base(st + 1), s1, g1);
+            if (st + 3 < nsteps) panel_load(c4, v4, step_base(st + 3), lane, s1);
+        }
+        sum(step_base(st), g0);
+        if (st + 2 < nsteps) {
+            gather(step_base(st + 2), s0, g0);
+            if (st + 4 < nsteps) panel_load(c4, v4, step_base(st + 4), lane, s0);
+        }
+        if (st + 1 < nsteps) sum(step_base(st + 1), g1);
     }
     for (int i = lane; i < n; i += kWave) y[row0 + i] = ys[i];
 }
