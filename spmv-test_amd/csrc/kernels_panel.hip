@@ -235,7 +235,8 @@ struct GatherRegs {   // one step between its gathers and its sums
     float xv[kVec][4];
     float val[kVec][4];
     int row[kVec][4];
-    bool simple[kVec];
+    bool simple[kVec];     // wave-uniform: group j holds 4 x 64 distinct rows
+    bool straddle[kVec];   // wave-uniform: group j spans two tiles
     bool interior;
 };
 
@@ -303,9 +304,8 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
             // the four instructions of group j cover 256 consecutive stream positions: one tile, no join bits,
             // all valid -> 64 distinct rows each
             const unsigned joins = (r.c[j][0] | r.c[j][1] | r.c[j][2] | r.c[j][3]) & kJoinBit;
-            g.simple[j] = g.interior &&
-                          __builtin_amdgcn_readlane(pv[j][0], 0) == __builtin_amdgcn_readlane(pv[j][3], 63) &&
-                          __ballot(joins != 0u) == 0ull;
+            g.straddle[j] = __builtin_amdgcn_readlane(pv[j][0], 0) != __builtin_amdgcn_readlane(pv[j][3], 63);
+            g.simple[j] = g.interior && !g.straddle[j] && __ballot(joins != 0u) == 0ull;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int64_t col = ((int64_t)pv[j][q] << pw_bits) | (int64_t)(r.c[j][q] & kColMask);
@@ -329,10 +329,17 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
             } else {
                 // a tile boundary, a repeated row or the ragged end of the stream: LDS atomics (one wave, in
                 // instruction order).  Cheaper than sorting the cases out lane by lane -- measured, DESIGN.md.
+                const int kq = base + (j * kWave + lane) * 4;
+                const bool all4 = g.interior || (kq >= s && kq + 3 < e);
+                if (all4 && g.row[j][0] == g.row[j][3] && !g.straddle[j]) {
+                    // my four consecutive nonzeros are one row (rows ascend inside a tile): one add
+                    atomicAdd(&ys[g.row[j][0]], (g.val[j][0] * g.xv[j][0] + g.val[j][1] * g.xv[j][1]) +
+                                                    (g.val[j][2] * g.xv[j][2] + g.val[j][3] * g.xv[j][3]));
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = base + (j * kWave + lane) * 4 + q;
-                    if (g.interior || (k >= s && k < e)) atomicAdd(&ys[g.row[j][q]], g.val[j][q] * g.xv[j][q]);
+                    for (int q = 0; q < 4; ++q)
+                        if (g.interior || (kq + q >= s && kq + q < e))
+                            atomicAdd(&ys[g.row[j][q]], g.val[j][q] * g.xv[j][q]);
                 }
             }
         }
