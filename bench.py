@@ -302,7 +302,7 @@ def main():
             Ae = capi.CsrMatrix.from_device(we.rows, we.cols, e_rp, e_ci, e_va)
             be = W.algorithmic_bytes(we.rows, we.cols, we.nnz)
             best = None
-            for vn in ("adaptive", "tiled", "vector"):
+            for vn in ("adaptive", "tiled", "vector") + (("panel",) if band == 0 else ()):
                 v = capi.VARIANTS[vn]
                 Ae.plan(v)
                 Ae.time(v, e_x, e_y, 3)

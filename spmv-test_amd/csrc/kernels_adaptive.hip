@@ -822,6 +822,19 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
     // once per matrix (the reference pays a host-side format build per launcher call).
     struct Cand { int block, maxpass; };
     const Cand cands[] = {{256, 2}, {512, 4}, {512, 8}, {1024, 6}, {1024, 12}};
+    {
+        // nothing to tune when no candidate can stage a single chunk (columns without locality: every trial
+        // would run the same global-gather kernel, 100 ms of trials at 2^28 nonzeros) -- SPMV_PANEL's case
+        const Cand widest[] = {{1024, 12}, {512, 8}, {256, 2}};
+        bool any = false;
+        for (const Cand &c : widest) {
+            int single = 0, full = 0;
+            int rc0 = build_plan(h, c.block, c.maxpass, s, h.plan_tiled, &single, &full);
+            if (rc0) return rc0;
+            if (h.plan_tiled.nchunks == 0 || full > 0) { any = true; break; }
+        }
+        if (!any) return SPMV_OK;   // the (256, 2) plan built last stands; no 16-bit copy (nothing is staged)
+    }
     DevPtr<float> xt, yt;
     SPMV_HIP_TRY(xt.alloc((size_t)h.cols));
     SPMV_HIP_TRY(yt.alloc((size_t)h.rows));

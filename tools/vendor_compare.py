@@ -13,6 +13,7 @@ import argparse
 import ctypes
 import json
 import sys
+import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -98,14 +99,20 @@ def main():
 
         A = capi.CsrMatrix.from_device(w.rows, w.cols, d_rp, d_ci, d_va)
         ours = {}
-        for vname in ("scalar", "wave", "adaptive", "tiled"):
+        for vname in ("scalar", "wave", "adaptive", "tiled", "panel"):
             v = capi.VARIANTS[vname]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             A.plan(v)
+            torch.cuda.synchronize()
+            plan_ms = (time.perf_counter() - t0) * 1e3
             A.time(v, d_x, d_y, 3)
             ms = min(A.time(v, d_x, d_y, args.iters) for _ in range(3))
             ours[vname] = ms
             emit(workload=label, impl=f"this:{vname}", ms=round(ms, 4), GBs=round(B / ms / 1e6, 1),
-                 pct_of_8TBs=round(B / ms / 1e6 / 80, 2))
+                 pct_of_8TBs=round(B / ms / 1e6 / 80, 2), preprocess_ms=round(plan_ms, 3))
+        best_ours = min(ours, key=ours.get)
+        ours["best"] = ours[best_ours]
         A.run(capi.TILED, d_x, d_y)
         torch.cuda.synchronize()
         y_ours = d_y.clone()
@@ -155,7 +162,8 @@ def main():
             emit(workload=label, impl=f"rocsparse:{aname}", ms=round(best, 4), GBs=round(B / best / 1e6, 1),
                  pct_of_8TBs=round(B / best / 1e6 / 80, 2), preprocess_ms=round(prep_ms, 3),
                  workspace_bytes=int(size.value), max_abs_diff_vs_this=diff,
-                 this_tiled_speedup=round(best / ours["tiled"], 2))
+                 this_tiled_speedup=round(best / ours["tiled"], 2), this_best=best_ours,
+                 this_best_speedup=round(best / ours["best"], 2))
             del buf
             torch.cuda.synchronize()
             rs.L.rocsparse_destroy_spmat_descr(mat)
