@@ -5,14 +5,16 @@
 #   pass 3: --pmc WRITE_SIZE                 -> write side (separate pass, MI355X_MICROARCH.md "PMC slots")
 #   pass 4/5: the same two counters on tools/bin/ubench_stream (a pure 16-B/lane stream of known
 #             size: the calibration the guide asks for before quoting FETCH_SIZE absolutes)
+#   usage: tools/profile.sh <tag> ["extra bench.py args"]
 # Never combined with --sys-trace/--hip-trace (gpurun refuses that).  Output: gpurun_out/prof_<tag>/
 set -e
 TAG=${1:-r01}
+EXTRA=${2:-}          # extra bench.py arguments, e.g. "--variant panel --band 0"
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 5 --no-extras --no-cpu-baseline"
+ARGS="--steps 50 --warmup 5 --no-extras --no-cpu-baseline $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err

@@ -62,8 +62,19 @@ def main():
         kernels[k] = {"launches": n, "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
                       "hbm_bytes_per_launch": int(round((2 * f_kib + w_kib) * 1024))}
     # the plan autotunes over several instantiations of k_adaptive: the timed one has the most launches
-    dom = max((k for k in kernels if "k_adaptive" in k or "k_tiled16" in k), key=lambda k: kernels[k]["launches"])
-    summary = {"tag": tag, "command": "python3 bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline",
+    hot = ("k_panel(",) if bench["config"]["variant"] == "panel" else ("k_adaptive", "k_tiled16")
+    dom = max((k for k in kernels if any(h in k for h in hot)), key=lambda k: kernels[k]["launches"])
+    # the panel sweep covers the matrix in several launches of the same kernel ("launches=N" in the plan string):
+    # scale the per-launch counters to one SpMV so they compare with the algorithmic bytes of one SpMV
+    per_spmv = 1
+    if bench["config"]["variant"] == "panel" and "launches=" in bench.get("plan", ""):
+        per_spmv = int(bench["plan"].split("launches=")[1].split()[0])
+    if per_spmv > 1:
+        for key in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_per_launch"):
+            kernels[dom][key] = kernels[dom][key] * per_spmv
+        kernels[dom]["note"] = f"counters scaled by {per_spmv}: one SpMV = {per_spmv} launches of this kernel"
+    summary = {"tag": tag, "command": "python3 bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline"
+                                      + (" " + " ".join(sys.argv[2:]) if len(sys.argv) > 2 else ""),
                "workload": bench["config"]["workload"], "variant": bench["config"]["variant"],
                "calibration": {"kernel": ck, "known_read_bytes": int(known_read), "FETCH_SIZE_KiB": cal_f[ck][0],
                                "read_bytes_per_FETCH_KiB": round(read_factor * 1024, 2),
@@ -71,6 +82,8 @@ def main():
                                "known_write_bytes": int(known_write), "WRITE_SIZE_KiB": cal_w[ck][0],
                                "write_correction_factor": round(write_factor, 4)},
                "kernels": kernels, "dominant_kernel": dom,
+               "fabric_read_requests_per_nonzero(FETCH_KiB*1024/64/nnz)":
+                   round(kernels[dom]["FETCH_SIZE_KiB"] * 1024 / 64 / bench["config"]["nnz_per_gpu"], 4),
                "algorithmic_bytes_per_launch": bench["config"]["algorithmic_bytes_per_gpu"],
                "traffic_over_algorithmic": round(kernels[dom]["hbm_bytes_per_launch"] /
                                                  bench["config"]["algorithmic_bytes_per_gpu"], 4),
