@@ -5,8 +5,11 @@
 //              the same per-row operation order as SgemvCPU (src/tester.cpp:36-45),
 //              so results are bit-identical to the CPU oracle.
 //   k_wave     one 64-lane wavefront per row, lanes stride the row, __shfl_down tree
-//              role of wsp_kernel_v0/v1 (src/kernels/wsp.cu:4-56, 59-138): "one warp per
-//              output, butterfly reduce, lane 0 stores" -- re-derived for CSR and 64 lanes.
+//              role of wsp_kernel_v0 (src/kernels/wsp.cu:4-56): "one warp per output,
+//              butterfly reduce, lane 0 stores" -- re-derived for CSR and 64 lanes.
+//   k_wave_bundle  a wavefront per 64 consecutive rows: coalesced stream of their nonzeros,
+//              products parked in LDS, lane per short row, whole wave per long row
+//              role of wsp_kernel_v1 (src/kernels/wsp.cu:59-138), the reference's pipelined version.
 //   k_vector   G-lane groups per row (G = 2..32), the short-row member of the family
 //              role of asp_kernel_v* (src/kernels/asp.cu:6-211: many outputs per block).
 //
@@ -69,21 +72,16 @@ __device__ __forceinline__ float wave_reduce_sum(float v)
     return v;  // lane 0 holds the total
 }
 
+// one row by the whole wave: lanes stride the row (four 64-wide slices in flight per trip when PIPE), then the
+// __shfl_down tree; every lane returns the sum
 template <bool PIPE>
-__global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__restrict__ row_ptr,
-                                                 const int32_t *__restrict__ col_idx,
-                                                 const float *__restrict__ vals,
-                                                 const float *__restrict__ x, float *__restrict__ y)
+__device__ __forceinline__ float wave_row(int lane, int32_t b, int32_t e, const int32_t *__restrict__ col_idx,
+                                          const float *__restrict__ vals, const float *__restrict__ x)
 {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (r >= rows) return;  // wave-uniform
-    const int32_t b = row_ptr[r], e = row_ptr[r + 1];
     float acc = 0.0f;
     int32_t k = b + lane;
     if (PIPE) {
-        // four independent 64-wide slices in flight per trip: 8 streamed loads then
-        // 4 gathers are issued before the first use.
+        // 8 streamed loads then 4 gathers are issued before the first use
         float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         for (; k + 3 * kWave < e; k += 4 * kWave) {
             int32_t c0 = col_idx[k], c1 = col_idx[k + kWave], c2 = col_idx[k + 2 * kWave],
@@ -98,8 +96,78 @@ __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__
         acc = (acc + a1) + (a2 + a3);
     }
     for (; k < e; k += kWave) acc = fmaf(vals[k], x[col_idx[k]], acc);
-    acc = wave_reduce_sum(acc);
+    return wave_reduce_sum(acc);
+}
+
+// SPMV_WAVE: one 64-lane wavefront per row, the literal re-derivation of wsp_kernel_v0.
+__global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__restrict__ row_ptr,
+                                                 const int32_t *__restrict__ col_idx,
+                                                 const float *__restrict__ vals,
+                                                 const float *__restrict__ x, float *__restrict__ y)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (r >= rows) return;  // wave-uniform
+    const float acc = wave_row<false>(lane, row_ptr[r], row_ptr[r + 1], col_idx, vals, x);
     if (lane == 0) y[r] = acc;
+}
+
+// SPMV_WAVE_PIPE (the slot of wsp_kernel_v1, the reference's unrolled / prefetching version): a wavefront owns 64
+// consecutive rows.  When their nonzeros fit its LDS slice the wave streams the whole contiguous range with
+// coalesced loads (lane-consecutive nonzeros, the whole wave busy whatever the row lengths), parks the products,
+// and every lane then adds the products of ITS row in order; rows longer than a wavefront are added by all 64
+// lanes with the __shfl_down tree instead.  A bundle that does not fit is taken in as many consecutive rows as do; a
+// row that does not fit on its own goes through wave_row<true> (four slices in flight, straight from memory).
+constexpr int kBundleCap = 2048;   // products per wave: 8 KiB of LDS, 32 KiB per workgroup
+__global__ __launch_bounds__(kBlock) void k_wave_bundle(int64_t rows, const int32_t *__restrict__ row_ptr,
+                                                        const int32_t *__restrict__ col_idx,
+                                                        const float *__restrict__ vals,
+                                                        const float *__restrict__ x, float *__restrict__ y)
+{
+    __shared__ float prod_all[kBlock / kWave][kBundleCap];
+    const int lane = threadIdx.x & (kWave - 1);
+    float *prod = prod_all[threadIdx.x >> 6];
+    const int64_t r0 = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kWave;
+    if (r0 >= rows) return;  // wave-uniform; no workgroup barrier below
+    const int64_t r = r0 + lane;
+    const bool live = r < rows;
+    const int32_t b = row_ptr[live ? r : rows], e = row_ptr[live ? r + 1 : rows];
+    const int n = (int)((rows - r0 < kWave) ? rows - r0 : kWave);
+    // as many consecutive rows as fit the slice at a time (usually all 64); a row that does not fit on its own is
+    // added straight from memory by the whole wave, four slices in flight
+    int i0 = 0;
+    while (i0 < n) {
+        const int32_t sb = __shfl(b, i0);
+        const unsigned long long fit = __ballot(lane >= i0 && lane < n && e - sb <= kBundleCap);   // e ascends
+        const int cnt = __popcll(fit);
+        if (cnt == 0) {
+            const float acc = wave_row<true>(lane, sb, __shfl(e, i0), col_idx, vals, x);
+            if (lane == 0) y[r0 + i0] = acc;
+            ++i0;
+            continue;
+        }
+        const int i1 = i0 + cnt;
+        const int32_t se = __shfl(e, i1 - 1);
+        for (int32_t k = sb + lane; k < se; k += kWave) prod[k - sb] = vals[k] * x[col_idx[k]];
+        const bool mine = lane >= i0 && lane < i1;
+        const bool is_long = mine && e - b > kWave;
+        if (mine && !is_long) {
+            float acc = 0.0f;
+            for (int32_t k = b; k < e; ++k) acc += prod[k - sb];
+            y[r] = acc;
+        }
+        unsigned long long todo = __ballot(is_long);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int32_t lb = __shfl(b, src), le = __shfl(e, src);
+            float acc = 0.0f;
+            for (int32_t k = lb + lane; k < le; k += kWave) acc += prod[k - sb];
+            acc = wave_reduce_sum(acc);
+            if (lane == 0) y[r0 + src] = acc;
+        }
+        i0 = i1;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -156,12 +224,15 @@ int launch_wave(const spmv_csr &h, const float *x, float *y, bool pipelined, hip
     constexpr int kRowsPerBlock = kBlock / kWave;
     int64_t blocks = (h.rows + kRowsPerBlock - 1) / kRowsPerBlock;
     if (!grid_ok(blocks)) return SPMV_ERR_INVALID;
-    if (pipelined)
-        hipLaunchKernelGGL(k_wave<true>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
-                           h.d_col_idx, h.d_vals, x, y);
-    else
-        hipLaunchKernelGGL(k_wave<false>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
-                           h.d_col_idx, h.d_vals, x, y);
+    if (pipelined) {
+        const int64_t bundles = (h.rows + kWave - 1) / kWave;
+        const int64_t bblocks = (bundles + (kBlock / kWave) - 1) / (kBlock / kWave);
+        hipLaunchKernelGGL(k_wave_bundle, dim3((unsigned)(bblocks ? bblocks : 1)), dim3(kBlock), 0, s, h.rows,
+                           h.d_row_ptr, h.d_col_idx, h.d_vals, x, y);
+    } else {
+        hipLaunchKernelGGL(k_wave, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr, h.d_col_idx,
+                           h.d_vals, x, y);
+    }
     return check_launch("k_wave");
 }
 
