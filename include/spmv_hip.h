@@ -122,7 +122,10 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
  * excludes its host format build from TIME_KERNEL (e.g. wsp.cu:146 vs :167).
  * A plan snapshots the sparsity PATTERN (row_ptr, col_idx): with borrowed
  * arrays (spmv_csr_create_device) the pattern must not change afterwards;
- * vals are read live on every run and may be updated freely.
+ * vals are read live on every run and may be updated freely -- except by
+ * SPMV_PANEL, whose plan re-orders the nonzeros and keeps its own copy of the
+ * values (plan again after changing them; its layout also replaces col_idx and
+ * vals byte for byte in what a run reads, and is limited to 2^29 columns).
  * spmv_csr_run: enqueue y = A x on `stream` (a hipStream_t, NULL = default).
  * Asynchronous; d_x has cols floats, d_y has rows floats and is fully
  * overwritten.  No allocation, no synchronisation: graph-capturable. */
