@@ -55,7 +55,9 @@ enum spmv_variant {
                         /*   (bit-identical to SgemvCPU, src/tester.cpp:36-45)     */
     SPMV_WAVE = 1,      /* one 64-lane wavefront per row, __shfl_down reduction:   */
                         /*   wsp_kernel_v0         src/kernels/wsp.cu:4-56         */
-    SPMV_WAVE_PIPE = 2, /* same, 4-deep unrolled loads (software pipeline):        */
+    SPMV_WAVE_PIPE = 2, /* a wavefront per 64 rows: their nonzeros streamed        */
+                        /* coalesced, products parked in LDS, a lane per short row, */
+                        /* the wave + __shfl_down per long row (4 loads in flight): */
                         /*   wsp_kernel_v1         src/kernels/wsp.cu:59-138       */
     SPMV_VECTOR = 3,    /* 2..32-lane groups per row, width from mean row length:  */
                         /*   asp_kernel_v0/1/2     src/kernels/asp.cu:6-211        */
