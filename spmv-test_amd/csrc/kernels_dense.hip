@@ -5,7 +5,8 @@
 //                  A^T; an element is kept iff (v != 0.0f) (-0.0f dropped, NaN kept, :15);
 //                  column indices ascend inside a row (:12-20).  The reference does this as a
 //                  single-threaded stride-N host scan (0.69 s at 4096^2); here it is a
-//                  count / scan / fill over (column, row-slab) pairs with coalesced reads.
+//                  count / scan / fill over (column, 64-row slab) pairs: coalesced reads of A, the
+//                  fill transposes 64 x 64 tiles through LDS so every run of a CSR row is one write.
 //   dense_gemv     y[i] = sum_j x[j]*A[j*N+i]: the dense slots of the launcher API --
 //                  naive_kernel (naive.cu:4-11), tiling_kernel (tiling_smem.cu:4-32) and the
 //                  vendor slot cublas_gemv_gpu (cublas.cu:4-44).
@@ -13,29 +14,20 @@
 
 namespace spmv {
 
-constexpr int kSlabs = 64;  // row slabs of A processed in parallel per output column
+constexpr int kSlabRows = 64;  // A is cut into slabs of 64 rows; (output column, slab) pairs are counted and filled
 
-__device__ __forceinline__ void slab_range(int M, int s, int &j0, int &j1)
-{
-    const int per = (M + kSlabs - 1) / kSlabs;
-    j0 = s * per;
-    j1 = j0 + per;
-    if (j0 > M) j0 = M;
-    if (j1 > M) j1 = M;
-}
-
-// counts[i*kSlabs + s] = nonzeros of column i inside slab s
-__global__ __launch_bounds__(kBlock) void k_dense_count(int M, int N, const float *__restrict__ A,
+// counts[i*S + s] = nonzeros of column i inside slab s (rows [64 s, 64 s + 64)): thread per column, coalesced reads
+__global__ __launch_bounds__(kBlock) void k_dense_count(int M, int N, int S, const float *__restrict__ A,
                                                         int32_t *__restrict__ counts)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int s = blockIdx.y;
     if (i >= N) return;
-    int j0, j1;
-    slab_range(M, s, j0, j1);
+    const int j0 = s * kSlabRows;
+    const int j1 = j0 + kSlabRows < M ? j0 + kSlabRows : M;
     int cnt = 0;
     for (int j = j0; j < j1; ++j) cnt += (A[(size_t)j * N + i] != 0.0f) ? 1 : 0;
-    counts[(size_t)i * kSlabs + s] = cnt;
+    counts[(size_t)i * S + s] = cnt;
 }
 
 // In-place exclusive scan of n int32 by one 1024-thread workgroup; total -> *total_out.
@@ -66,39 +58,115 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(int64_t n, int32_t *__r
     if (t == 1023) *total_out = (int32_t)part[1023];
 }
 
+// Large inputs: a three-step scan over tiles of kScanTile elements -- tile sums, the one-workgroup scan above over
+// those sums, then a scan inside every tile started from its offset (the one-workgroup scan alone took 0.42 ms
+// for the 262 144 slab counts of a 4096 x 4096 matrix, more than the two passes over the matrix together).
+constexpr int kScanTile = 4096;   // 256 threads x 16 consecutive elements
+
+__global__ __launch_bounds__(kBlock) void k_scan_tile_sums(int64_t n, const int32_t *__restrict__ data,
+                                                           int32_t *__restrict__ sums)
+{
+    __shared__ int part[kBlock / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 16;
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (base + i < n) sum += data[base + i];
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(int64_t n, int32_t *__restrict__ data,
+                                                       const int32_t *__restrict__ offsets)
+{
+    __shared__ int part[kBlock];
+    const int t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)t * 16;
+    int v[16];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        v[i] = base + i < n ? data[base + i] : 0;
+        sum += v[i];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < kBlock; o <<= 1) {
+        const int a = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += a;
+        __syncthreads();
+    }
+    int run = offsets[blockIdx.x] + part[t] - sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (base + i < n) data[base + i] = run;
+        run += v[i];
+    }
+}
+
 int exclusive_scan_i32(int32_t *d_data, int64_t n, int32_t *d_total, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, n, d_data, d_total);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "k_exclusive_scan", __FILE__, __LINE__);
+    hipError_t e;
+    if (n <= 4 * kScanTile) {
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, n, d_data, d_total);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_exclusive_scan", __FILE__, __LINE__);
+        return SPMV_OK;
+    }
+    const int64_t tiles = (n + kScanTile - 1) / kScanTile;
+    DevPtr<int32_t> sums;
+    SPMV_HIP_TRY(sums.alloc((size_t)tiles));
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)tiles), dim3(kBlock), 0, s, n, d_data, sums.p);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_scan_tile_sums", __FILE__, __LINE__);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, tiles, sums.p, d_total);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_exclusive_scan", __FILE__, __LINE__);
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(kBlock), 0, s, n, d_data, sums.p);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_scan_tiles", __FILE__, __LINE__);
+    SPMV_HIP_TRY(hipStreamSynchronize(s));   // `sums` is freed on return
     return SPMV_OK;
 }
 
-// row_ptr[i] = offs[i*kSlabs] for i < N, row_ptr[N] = nnz
-__global__ void k_row_ptr_from_offsets(int N, const int32_t *__restrict__ offs, const int32_t *__restrict__ total,
-                                       int32_t *__restrict__ row_ptr)
+// row_ptr[i] = offs[i*S] for i < N, row_ptr[N] = nnz
+__global__ void k_row_ptr_from_offsets(int N, int S, const int32_t *__restrict__ offs,
+                                       const int32_t *__restrict__ total, int32_t *__restrict__ row_ptr)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) row_ptr[i] = offs[(size_t)i * kSlabs];
+    if (i < N) row_ptr[i] = offs[(size_t)i * S];
     else if (i == N) row_ptr[N] = *total;
 }
 
-__global__ __launch_bounds__(kBlock) void k_dense_fill(int M, int N, const float *__restrict__ A,
+// One workgroup per (64 output columns) x (one slab of 64 rows): the 64 x 64 tile of A is read with coalesced
+// rows into LDS, then every wave takes 16 of the columns: lane = row of the slab, the kept elements of a column are
+// ranked with a ballot and written as ONE contiguous run (ascending row = ascending CSR column, matrix_csr.cpp:12-20).
+__global__ __launch_bounds__(kBlock) void k_dense_fill(int M, int N, int S, const float *__restrict__ A,
                                                        const int32_t *__restrict__ offs,
                                                        int32_t *__restrict__ col_idx, float *__restrict__ vals)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float tile[kSlabRows][kWave + 1];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * kWave;
     const int s = blockIdx.y;
-    if (i >= N) return;
-    int j0, j1;
-    slab_range(M, s, j0, j1);
-    int32_t p = offs[(size_t)i * kSlabs + s];
-    for (int j = j0; j < j1; ++j) {
-        const float v = A[(size_t)j * N + i];
-        if (v != 0.0f) {
+    const int j0 = s * kSlabRows;
+    for (int jj = w; jj < kSlabRows; jj += kBlock / kWave) {
+        const int j = j0 + jj;
+        tile[jj][lane] = (j < M && i0 + lane < N) ? A[(size_t)j * N + i0 + lane] : 0.0f;
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    constexpr int kColsPerWave = kWave / (kBlock / kWave);
+    for (int c = w * kColsPerWave; c < (w + 1) * kColsPerWave; ++c) {
+        if (i0 + c >= N) break;   // wave-uniform
+        const float v = tile[lane][c];
+        const bool keep = v != 0.0f;   // rows past M were loaded as 0
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int32_t p = offs[(size_t)(i0 + c) * S + s] + __popcll(m & lt);
             vals[p] = v;
-            col_idx[p] = j;
-            ++p;
+            col_idx[p] = j0 + lane;
         }
     }
 }
@@ -115,20 +183,23 @@ int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out
     int rc;
     DevPtr<int32_t> counts, total, row_ptr, col;
     DevPtr<float> val;
-    const size_t ncnt = (size_t)N * kSlabs;
+    const int S = M > 0 ? (M + kSlabRows - 1) / kSlabRows : 1;
+    const size_t ncnt = (size_t)N * (size_t)S;
+    if (S > 65535) {
+        set_error("dense_to_csr: M = %d exceeds the 64 x 65535 rows one launch covers", M);
+        return SPMV_ERR_INVALID;
+    }
     SPMV_HIP_TRY(counts.alloc(ncnt));
     SPMV_HIP_TRY(total.alloc(1));
     SPMV_HIP_TRY(row_ptr.alloc((size_t)N + 1));
     SPMV_HIP_TRY(hipMemsetAsync(total.p, 0, sizeof(int32_t), s));
-    const int gx = (N + kBlock - 1) / kBlock;
-    const dim3 grid(gx ? gx : 1, kSlabs);
     if (N > 0) {
-        hipLaunchKernelGGL(k_dense_count, grid, dim3(kBlock), 0, s, M, N, d_A, counts.p);
+        const int gx = (N + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_dense_count, dim3(gx, S), dim3(kBlock), 0, s, M, N, S, d_A, counts.p);
         if ((rc = check_launch("k_dense_count"))) return rc;
-        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, (int64_t)ncnt, counts.p, total.p);
-        if ((rc = check_launch("k_exclusive_scan"))) return rc;
+        if ((rc = exclusive_scan_i32(counts.p, (int64_t)ncnt, total.p, s))) return rc;
     }
-    hipLaunchKernelGGL(k_row_ptr_from_offsets, dim3((N + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, N,
+    hipLaunchKernelGGL(k_row_ptr_from_offsets, dim3((N + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, N, S,
                        counts.p, total.p, row_ptr.p);
     if ((rc = check_launch("k_row_ptr_from_offsets"))) return rc;
     int32_t nnz = 0;
@@ -137,7 +208,8 @@ int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out
     SPMV_HIP_TRY(col.alloc((size_t)nnz));
     SPMV_HIP_TRY(val.alloc((size_t)nnz));
     if (N > 0 && nnz > 0) {
-        hipLaunchKernelGGL(k_dense_fill, grid, dim3(kBlock), 0, s, M, N, d_A, counts.p, col.p, val.p);
+        hipLaunchKernelGGL(k_dense_fill, dim3((N + kWave - 1) / kWave, S), dim3(kBlock), 0, s, M, N, S, d_A, counts.p,
+                           col.p, val.p);
         if ((rc = check_launch("k_dense_fill"))) return rc;
     }
     SPMV_HIP_TRY(hipStreamSynchronize(s));
@@ -191,6 +263,17 @@ __global__ __launch_bounds__(kBlock) void k_gemv_xtile(int M, int N, const float
             }
     }
     if (i < N) y[i] = acc;
+}
+
+constexpr int kSlabs = 64;  // dense GEMV: row slabs of A processed in parallel per output column
+
+__device__ __forceinline__ void slab_range(int M, int s, int &j0, int &j1)
+{
+    const int per = (M + kSlabs - 1) / kSlabs;
+    j0 = s * per;
+    j1 = j0 + per;
+    if (j0 > M) j0 = M;
+    if (j1 > M) j1 = M;
 }
 
 // mode 2: rows of A split into kSlabs slabs -> N/256 x kSlabs workgroups stream A with
