@@ -11,7 +11,7 @@
 // second launch takes the next set of row blocks): a wave that starts late is out of step with the others, and the
 // L2 then holds several panels instead of one (measured with tools/ubench_panel.hip: 2.3 ms instead of 1.2 ms on
 // the 16Mi x 16Mi / 2^28-nonzero uniform workload).  Low occupancy is deliberate for the same reason -- 4 waves per
-// CU, each with 2 x 16 sixteen-byte loads in flight, beat 16 or 32 waves per CU.
+// CU, each with dozens of sixteen-byte loads and gathers in flight, beat 16 or 32 waves per CU.
 //
 // The reference's tiled format (TCSRMatrix, src/tcsr.cpp:5-38, multiplied by csr_tiling_kernel,
 // src/kernels/csr_tiling.cu:24-114: 32 x 32 tiles, x tile and tile values in shared memory) is the same idea at
@@ -42,8 +42,11 @@ constexpr unsigned kColMask = (1u << kColBits) - 1;
 constexpr unsigned kJoinBit = 1u << kColBits;   // this nonzero and the one 4 places before it in its tile share a row
 constexpr int kRowShift = kColBits + 1;
 constexpr int kWavesPerWg = 2;             // 76 KiB of LDS per workgroup -> 2 workgroups = 4 waves per CU
-constexpr int kVec = 4;                    // 16-byte vectors per lane per step and per array
-constexpr int kStep = kWave * 4 * kVec;    // 1024 nonzeros per wave per step
+#ifndef SPMV_PANEL_VEC
+#define SPMV_PANEL_VEC 8
+#endif
+constexpr int kVec = SPMV_PANEL_VEC;       // 16-byte vectors per lane per step and per array
+constexpr int kStep = kWave * 4 * kVec;    // 2048 nonzeros per wave per step (8 vectors: +4 % over 4, A/B on c3/c4)
 constexpr int kMaxPanels = 4096;
 
 using u4 = unsigned __attribute__((ext_vector_type(4)));
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
     const int nsteps = (e - k0 + kStep - 1) / kStep;
     int pdone = 0;   // boundaries tp[1..pdone] lie at or before the current step
 
-    // Two stages per step, one step apart, so that a step's 16 gathers per lane are in flight while the previous
+    // Two stages per step, one step apart, so that a step's 32 gathers per lane are in flight while the previous
     // step is being summed (one wave per SIMD: nothing else hides their latency).
     //   gather(step): panel of every element, issue the x loads, keep what the sums need (the stream registers are
     //                 free for the next load right after);

@@ -86,6 +86,21 @@ def test_panel_plan_copies_the_values(pkg, oracle, gpu):
     assert np.array_equal(y1, 2.0 * y0)
     assert np.array_equal(prob.run(pkg.capi.TILED).view(np.uint32), prob.run(pkg.capi.TILED).view(np.uint32))
 
+
+def test_panel_refuses_more_columns_than_its_format_holds(pkg, gpu):
+    """packed[] keeps 17 bits of column-in-panel and the plan at most 4096 panels: 2^29 columns per handle."""
+    import torch
+    capi = pkg.capi
+    rp = torch.tensor([0, 1, 2], dtype=torch.int32, device=gpu)
+    ci = torch.tensor([5, (1 << 30) - 1, 0, 0], dtype=torch.int32, device=gpu)[:2]
+    va = torch.ones(4, dtype=torch.float32, device=gpu)[:2]
+    A = capi.CsrMatrix.from_device(2, 1 << 30, rp, ci, va)
+    with pytest.raises(capi.SpmvError) as e:
+        A.plan(capi.PANEL)
+    assert e.value.status == capi.ERR_INVALID and "panels" in str(e.value)
+    A.plan(capi.TILED)            # the other variants take it
+    A.close()
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
