@@ -400,7 +400,8 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
         }
 
         // ---- row pointers of this lane's first segment, in flight together with the stream
-        //      (ADAPTIVE only: TILED has no registers to spare for them)
+        //      (ADAPTIVE and k_tiled16 only: the 32-bit TILED form spills 20 bytes with them, wherever they
+        //      are issued, and runs 5 % slower -- A/B)
         int32_t rb0 = 0, re0 = 0;
         if (!TILED && tid <= m) {
             rb0 = row_ptr[tid == 0 ? lb0 : lb0 + tid - 1];  // lb0 <= rows and row_ptr[rows] = nnz
@@ -529,6 +530,14 @@ __global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols
         for (int j = 0; j < kVec; ++j) vv[j] = __builtin_nontemporal_load(&v4[j * BLOCK + tid]);
     }
 
+    // the bounds of this lane's first segment ride along with the stream (they only depend on chunk_lb): two
+    // registers; without them the row phase starts with an exposed L2/HBM round trip (+3.4 % at c4, A/B)
+    int32_t rb0 = 0, re0 = 0;
+    if (tid <= m) {
+        rb0 = row_ptr[tid == 0 ? lb0 : lb0 + tid - 1];
+        re0 = tid == 0 ? 0 : row_ptr[lb0 + tid];
+    }
+
     // ---- gather x from the staged slices (every column of the chunk lies in [w0, w0+wlen))
     f4 xv[kVec];
 #pragma unroll
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols
         smem[p0 + 3] = vv[j][3] * xv[j][3];
     }
     __syncthreads();
-    reduce_chunk<BLOCK, false>(smem, sh, tid, c, lb0, m, base, lim, row_ptr, y, carry, 0, 0);
+    reduce_chunk<BLOCK, true>(smem, sh, tid, c, lb0, m, base, lim, row_ptr, y, carry, rb0, re0);
 }
 
 // plan: 16-bit offsets of every eligible chunk (full chunk, whole span staged, span < 65536), in the
