@@ -1000,7 +1000,10 @@ int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hip
     }
     const bool persist = p.persist;
     int rc;
-    if (!tiled) rc = launch_either<256, false>(persist, h, p, x, y, s);
+    // a tiled plan that stages nothing runs the plain kernel (same chunks; it keeps the row-bound prefetch the
+    // 32-bit tiled form has no registers for)
+    const bool nothing_staged = tiled && p.block == 256 && p.staged_full == 0 && !p.d_col16;
+    if (!tiled || nothing_staged) rc = launch_either<256, false>(persist, h, p, x, y, s);
     else if (p.block == 256) rc = launch_either<256, true>(persist, h, p, x, y, s);
     else if (p.block == 512) rc = launch_either<512, true>(persist, h, p, x, y, s);
     else rc = launch_either<1024, true>(persist, h, p, x, y, s);
