@@ -53,7 +53,7 @@ __host__ __device__ constexpr int max_long(int block) { return chunk_of(block) /
 #ifndef SPMV_T_HUGE
 #define SPMV_T_HUGE 512
 #endif
-constexpr int kHugeSeg = SPMV_T_HUGE;  // segments longer than this are summed by the whole workgroup
+constexpr int kHugeSeg = SPMV_T_HUGE;  // segments longer than this are summed by one wavefront each
 __host__ __device__ constexpr int max_huge(int block) { return chunk_of(block) / (kHugeSeg + 1) + 2; }
 
 __device__ __forceinline__ int pad_idx(int i) { return i + (i >> 5); }
@@ -196,14 +196,13 @@ template <int BLOCK>
 struct ChunkShared {
     int2 long_seg[max_long(BLOCK)];  // {segment id, first product | end product << 16}
     int2 huge_seg[max_huge(BLOCK)];
-    float wave_part[BLOCK / kWave];
     int long_count, huge_count;
 };
 
 // The row reduction of one chunk, products already staged in `smem` (a barrier behind them):
 //   short segments (<= kShortSeg): one lane each, sequential (the oracle's order);
 //   17..kHugeSeg: queued in LDS with their bounds, summed by kGroup-lane groups (__shfl_down tree);
-//   longer (a power-law row can fill the chunk): the whole workgroup.
+//   longer (a power-law row can fill the chunk): one wavefront each.
 // PREF: this lane's first row bounds were prefetched into rb0/re0.
 template <int BLOCK, bool PREF>
 __device__ __forceinline__ void reduce_chunk(const float *smem, ChunkShared<BLOCK> &sh, int tid, int c, int lb0, int m,
@@ -250,23 +249,28 @@ __device__ __forceinline__ void reduce_chunk(const float *smem, ChunkShared<BLOC
         }
     }
 
+    // longer segments: one WAVE each, lanes striding the segment (no workgroup barrier: a chunk of a dense-ish
+    // matrix is a handful of such rows and the waves take them side by side; a single segment that fills the chunk
+    // costs one wave 256 LDS reads per lane)
     const int nhuge = sh.huge_count;
-    for (int i = 0; i < nhuge; ++i) {
+    const int lane = tid & (kWave - 1);
+    for (int i = tid >> 6; i < nhuge; i += BLOCK / kWave) {
         const int2 q = sh.huge_seg[i];
         const int qe = (int)((unsigned)q.y >> 16);
-        float acc = 0.0f;
-        for (int k = (q.y & 0xffff) + tid; k < qe; k += BLOCK) acc += smem[pad_idx(k)];
+        float a0 = 0.0f, a1 = 0.0f;
+        int k = (q.y & 0xffff) + lane;
+        for (; k + kWave < qe; k += 2 * kWave) {
+            a0 += smem[pad_idx(k)];
+            a1 += smem[pad_idx(k + kWave)];
+        }
+        if (k < qe) a0 += smem[pad_idx(k)];
+        float acc = a0 + a1;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
-        if ((tid & (kWave - 1)) == 0) sh.wave_part[tid >> 6] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            float tot = 0.0f;
-            for (int w = 0; w < BLOCK / kWave; ++w) tot += sh.wave_part[w];
-            if (q.x == 0) carry[c] = tot;
-            else y[(int64_t)lb0 + q.x - 1] = tot;
+        if (lane == 0) {
+            if (q.x == 0) carry[c] = acc;
+            else y[(int64_t)lb0 + q.x - 1] = acc;
         }
-        __syncthreads();
     }
 }
 

@@ -99,7 +99,10 @@ __device__ __forceinline__ float wave_row(int lane, int32_t b, int32_t e, const 
     return wave_reduce_sum(acc);
 }
 
-// SPMV_WAVE: one 64-lane wavefront per row, the literal re-derivation of wsp_kernel_v0.
+// SPMV_WAVE: one 64-lane wavefront per row, the literal re-derivation of wsp_kernel_v0 (PIPE = false).  PIPE = true
+// is what SPMV_WAVE_PIPE runs on matrices of long rows (mean > 32 nonzeros, the reference's own 4096 x 4096 / 50 %
+// regime): the same mapping with four slices in flight per trip.
+template <bool PIPE>
 __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__restrict__ row_ptr,
                                                  const int32_t *__restrict__ col_idx,
                                                  const float *__restrict__ vals,
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (r >= rows) return;  // wave-uniform
-    const float acc = wave_row<false>(lane, row_ptr[r], row_ptr[r + 1], col_idx, vals, x);
+    const float acc = wave_row<PIPE>(lane, row_ptr[r], row_ptr[r + 1], col_idx, vals, x);
     if (lane == 0) y[r] = acc;
 }
 
@@ -224,13 +227,19 @@ int launch_wave(const spmv_csr &h, const float *x, float *y, bool pipelined, hip
     constexpr int kRowsPerBlock = kBlock / kWave;
     int64_t blocks = (h.rows + kRowsPerBlock - 1) / kRowsPerBlock;
     if (!grid_ok(blocks)) return SPMV_ERR_INVALID;
-    if (pipelined) {
+    // bundles of 64 rows pay off while they fit a wave's LDS slice (mean row length <= 32); beyond that a bundle
+    // would serialise 64 long rows on one wave (4096 x 4096 at 50 %: 64 waves for the whole chip, 17x slower)
+    const bool bundle = pipelined && h.nnz <= 32 * h.rows;
+    if (pipelined && !bundle) {
+        hipLaunchKernelGGL(k_wave<true>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr, h.d_col_idx,
+                           h.d_vals, x, y);
+    } else if (bundle) {
         const int64_t bundles = (h.rows + kWave - 1) / kWave;
         const int64_t bblocks = (bundles + (kBlock / kWave) - 1) / (kBlock / kWave);
         hipLaunchKernelGGL(k_wave_bundle, dim3((unsigned)(bblocks ? bblocks : 1)), dim3(kBlock), 0, s, h.rows,
                            h.d_row_ptr, h.d_col_idx, h.d_vals, x, y);
     } else {
-        hipLaunchKernelGGL(k_wave, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr, h.d_col_idx,
+        hipLaunchKernelGGL(k_wave<false>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr, h.d_col_idx,
                            h.d_vals, x, y);
     }
     return check_launch("k_wave");

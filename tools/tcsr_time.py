@@ -41,7 +41,7 @@ def main():
         b_csr = W.algorithmic_bytes(N, M, nnz)
         rec = dict(M=M, N=N, zero=zero, nnz=nnz, tcsr_ms=round(ms_t, 4), tcsr_format_GBs=round(b_tcsr / ms_t / 1e6, 1),
                    tcsr_csr_equiv_GBs=round(b_csr / ms_t / 1e6, 1), tcsr_bytes=b_tcsr, csr_bytes=b_csr)
-        for vn in ("wave_pipe", "adaptive", "tiled"):
+        for vn in ("scalar", "wave", "wave_pipe", "vector", "adaptive", "tiled"):
             v = capi.VARIANTS[vn]
             c.plan(v)
             ms = timeit(lambda: c.run(v, x, y))
