@@ -187,6 +187,25 @@ def test_malformed_csr_is_refused_before_any_kernel_sees_it(pkg, gpu):
         assert y.tolist() == [11.0, 20.0]
 
 
+
+def test_scalar_stays_bit_identical_on_long_rows(pkg, oracle, gpu):
+    """Rows of ~1000-2000 nonzeros (the reference's own 50 %-dense regime) take the wavefront-per-row form of the
+    SCALAR variant (k_scalar_long); its in-order readlane chain must reproduce the host loop bit for bit, ragged row
+    ends and -0.0 / tiny values included."""
+    W = pkg.workloads
+    for (M, N, zero, seed) in [(2048, 300, 0.5, 5), (4096, 129, 0.25, 6), (1000, 64, 0.0, 7)]:
+        A, x = W.dense_random(M, N, zero, seed=seed)
+        A[::7, ::3] *= 1e-30
+        A[5::11, 1::5] = -0.0
+        rp, ci, va = oracle.csr_from_dense(A)
+        assert len(ci) > 64 * N
+        prob = DeviceProblem(pkg, gpu, N, M, rp, ci, va, x)
+        y = prob.run(pkg.capi.SCALAR)
+        y_seq = oracle.spmv(rp, ci, va, x)
+        assert np.array_equal(y.view(np.uint32), y_seq.view(np.uint32)), (M, N, zero)
+        assert np.array_equal(y, oracle.sgemv_dense(A, x))        # and to the dense SgemvCPU loop itself
+        prob.A.close()
+
 def test_results_are_deterministic_run_to_run(pkg, oracle, gpu):
     w = pkg.workloads.config("c3", scale=1 / 32)
     prob = synth_problem(pkg, oracle, gpu, w)
