@@ -151,8 +151,11 @@ SPMV_API int spmv_csr_time(spmv_csr_t *h, int variant, const float *d_x, float *
                   void *stream, float *ms_per_launch);
 
 /* Host-buffer convenience used by the C++ launchers: upload x (cols floats),
- * plan if needed, run once between HIP events, download y (rows floats).
- * Synchronous.  *kernel_ms (may be NULL) receives the event time of the run.
+ * plan if needed, one untimed launch (code-object load, caches), one launch
+ * between HIP events, download y (rows floats).  Synchronous.  *kernel_ms (may
+ * be NULL) receives the event time of the second launch (the reference times a
+ * single cold launch, kernel.hpp:31-48).  The dense and tcsr *_host calls do
+ * the same.
  * replaces: the malloc/memcpy/TIME_KERNEL/memcpy/free body of a reference
  * launcher (e.g. csr_naive.cu:36-73). */
 SPMV_API int spmv_csr_run_host(spmv_csr_t *h, int variant, const float *x_host, float *y_host,

@@ -368,6 +368,9 @@ int spmv_csr_run_host(spmv_csr_t *h, int variant, const float *x_host, float *y_
     SPMV_HIP_TRY(hipMemcpy(dx.p, x_host, sizeof(float) * (size_t)h->cols, hipMemcpyHostToDevice));
     SPMV_HIP_TRY(hipEventCreate(&ev.a));
     SPMV_HIP_TRY(hipEventCreate(&ev.b));
+    // one untimed launch first: the reference's TIME_KERNEL (kernel.hpp:31-48) times a single COLD launch, code
+    // object load included; here the printed figure is the kernel
+    if ((rc = spmv_csr_run(h, variant, (const float *)dx.p, (float *)dy.p, nullptr))) return rc;
     SPMV_HIP_TRY(hipDeviceSynchronize());
     SPMV_HIP_TRY(hipEventRecord(ev.a, nullptr));
     rc = spmv_csr_run(h, variant, (const float *)dx.p, (float *)dy.p, nullptr);
@@ -400,6 +403,7 @@ int spmv_dense_gemv_host(int M, int N, const float *A_host, const float *x_host,
     SPMV_HIP_TRY(hipMemcpy(dx.p, x_host, sizeof(float) * (size_t)M, hipMemcpyHostToDevice));
     SPMV_HIP_TRY(hipEventCreate(&ev.a));
     SPMV_HIP_TRY(hipEventCreate(&ev.b));
+    if ((rc = dense_gemv(M, N, (const float *)dA.p, (const float *)dx.p, (float *)dy.p, mode, nullptr))) return rc;  // warm
     SPMV_HIP_TRY(hipDeviceSynchronize());
     SPMV_HIP_TRY(hipEventRecord(ev.a, nullptr));
     rc = dense_gemv(M, N, (const float *)dA.p, (const float *)dx.p, (float *)dy.p, mode, nullptr);
@@ -475,9 +479,11 @@ int spmv_tcsr_run_host(const spmv_tcsr_t *h, const float *x_host, float *y_host,
     SPMV_HIP_TRY(hipMemcpy(dx.p, x_host, sizeof(float) * (size_t)M, hipMemcpyHostToDevice));
     SPMV_HIP_TRY(hipEventCreate(&ev.a));
     SPMV_HIP_TRY(hipEventCreate(&ev.b));
+    int rc = tcsr_run(*h, (const float *)dx.p, (float *)dy.p, nullptr);   // warm
+    if (rc) return rc;
     SPMV_HIP_TRY(hipDeviceSynchronize());
     SPMV_HIP_TRY(hipEventRecord(ev.a, nullptr));
-    int rc = tcsr_run(*h, (const float *)dx.p, (float *)dy.p, nullptr);
+    rc = tcsr_run(*h, (const float *)dx.p, (float *)dy.p, nullptr);
     SPMV_HIP_TRY(hipEventRecord(ev.b, nullptr));
     SPMV_HIP_TRY(hipEventSynchronize(ev.b));
     if (rc) return rc;

@@ -330,16 +330,19 @@ int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int
         return check_launch("k_gemv_xtile");
     }
     if (mode == 2 || mode == 3) {
-        float *d_part = nullptr;
-        SPMV_HIP_TRY(hipMallocAsync((void **)&d_part, sizeof(float) * (size_t)kSlabs * N, s));
+        // the per-slab partials: a plain allocation, released after the stream has drained (the stream-ordered
+        // allocator on the legacy NULL stream handed a second call memory the first call's kernels were still
+        // using: 64 wrong outputs in 17 of 25 runs of the tester at 1024 x 768)
+        DevPtr<float> part;
+        SPMV_HIP_TRY(part.alloc((size_t)kSlabs * N));
         if (mode == 3)
-            hipLaunchKernelGGL(k_gemv_split<true>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, d_part);
+            hipLaunchKernelGGL(k_gemv_split<true>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, part.p);
         else
-            hipLaunchKernelGGL(k_gemv_split<false>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, d_part);
+            hipLaunchKernelGGL(k_gemv_split<false>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, part.p);
         if ((rc = check_launch("k_gemv_split"))) return rc;
-        hipLaunchKernelGGL(k_gemv_combine, dim3(blocks), dim3(kBlock), 0, s, N, d_part, d_y);
+        hipLaunchKernelGGL(k_gemv_combine, dim3(blocks), dim3(kBlock), 0, s, N, part.p, d_y);
         if ((rc = check_launch("k_gemv_combine"))) return rc;
-        SPMV_HIP_TRY(hipFreeAsync(d_part, s));
+        SPMV_HIP_TRY(hipStreamSynchronize(s));
         return SPMV_OK;
     }
     set_error("spmv_dense_gemv: unknown mode %d", mode);
