@@ -18,6 +18,32 @@
 
 namespace spmv {
 
+// One row by the whole wave IN THE ORACLE'S ORDER: 64 lane-consecutive products per trip (coalesced, each rounded
+// once, the next trip's loads already in flight), then added in order -- lane 0's first -- through a readlane chain.
+// Every lane returns the sum.
+__device__ __forceinline__ float scalar_row_by_wave(int lane, int32_t b, int32_t e, const int32_t *__restrict__ col_idx,
+                                                    const float *__restrict__ vals, const float *__restrict__ x)
+{
+#pragma clang fp contract(off)
+    float acc = 0.0f;       // wave-uniform
+    int32_t k = b + lane;
+    float p = k < e ? x[col_idx[k]] * vals[k] : 0.0f;
+    for (int32_t k0 = b; k0 < e; k0 += kWave) {
+        const int32_t kn = k0 + kWave + lane;
+        const float pn = kn < e ? x[col_idx[kn]] * vals[kn] : 0.0f;   // next trip, in flight during the chain
+        const int n = e - k0 < kWave ? e - k0 : kWave;
+        if (n == kWave) {
+#pragma unroll
+            for (int l = 0; l < kWave; ++l)
+                acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), l));
+        } else {
+            for (int l = 0; l < n; ++l) acc = acc + __shfl(p, l);
+        }
+        p = pn;
+    }
+    return acc;
+}
+
 // ---------------------------------------------------------------------------
 // k_scalar: ONE THREAD PER ROW, terms added in ascending k with an unfused multiply and add --
 // exactly the arithmetic of the host loop, so y is bit-identical to SgemvCPU / the CSR walk.
@@ -54,13 +80,27 @@ __global__ __launch_bounds__(kBlock) void k_scalar(int64_t rows, const int32_t *
             for (int32_t k = b; k < e; ++k) acc = acc + prod[k - wb];
             y[r] = acc;
         }
-    } else if (r < rows) {
-        float acc = 0.0f;
-        for (int32_t k = b; k < e; ++k) {
-            const float p = x[col_idx[k]] * vals[k];
-            acc = acc + p;
+    } else {
+        // the workgroup's rows hold more than the LDS buffer: rows of up to 256 nonzeros by their own thread (the
+        // plain loop), longer ones -- a power-law row can hold 65 536 -- one at a time by the whole wave, in order,
+        // through the readlane chain of k_scalar_long below (c3: 39.6 ms -> see DESIGN.md)
+        const int lane = threadIdx.x & (kWave - 1);
+        const bool is_long = e - b > 256;
+        if (r < rows && !is_long) {
+            float acc = 0.0f;
+            for (int32_t k = b; k < e; ++k) {
+                const float p = x[col_idx[k]] * vals[k];
+                acc = acc + p;
+            }
+            y[r] = acc;
         }
-        y[r] = acc;
+        unsigned long long todo = __ballot(is_long);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const float acc = scalar_row_by_wave(lane, __shfl(b, src), __shfl(e, src), col_idx, vals, x);
+            if (lane == 0) y[r - lane + src] = acc;   // r - lane: the wave's first row
+        }
     }
 }
 
@@ -74,27 +114,10 @@ __global__ __launch_bounds__(kBlock) void k_scalar_long(int64_t rows, const int3
                                                         const float *__restrict__ vals,
                                                         const float *__restrict__ x, float *__restrict__ y)
 {
-#pragma clang fp contract(off)
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (r >= rows) return;  // wave-uniform
-    const int32_t b = row_ptr[r], e = row_ptr[r + 1];
-    float acc = 0.0f;       // wave-uniform
-    int32_t k = b + lane;
-    float p = k < e ? x[col_idx[k]] * vals[k] : 0.0f;
-    for (int32_t k0 = b; k0 < e; k0 += kWave) {
-        const int32_t kn = k0 + kWave + lane;
-        const float pn = kn < e ? x[col_idx[kn]] * vals[kn] : 0.0f;   // next trip, in flight during the chain
-        const int n = e - k0 < kWave ? e - k0 : kWave;
-        if (n == kWave) {
-#pragma unroll
-            for (int l = 0; l < kWave; ++l)
-                acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), l));
-        } else {
-            for (int l = 0; l < n; ++l) acc = acc + __shfl(p, l);
-        }
-        p = pn;
-    }
+    const float acc = scalar_row_by_wave(lane, row_ptr[r], row_ptr[r + 1], col_idx, vals, x);
     if (lane == 0) y[r] = acc;
 }
 
