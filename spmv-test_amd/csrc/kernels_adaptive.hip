@@ -365,27 +365,24 @@ __device__ __forceinline__ void stage_slice(const float *__restrict__ x, int64_t
     }
 }
 
+// The body of k_adaptive for workgroup `bid` of `grid` (a device function so that k_tiled_mixed can run it beside
+// the 16-bit body in one launch).  smem: one dynamic LDS region, used twice: first as the x window (TILED), then
+// -- after the gathers have landed in registers -- as the product staging buffer.
 template <int BLOCK, bool TILED, bool PERSIST>
-__global__ __launch_bounds__(BLOCK, waves_per_simd(BLOCK, PERSIST))
-void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
-                                                       const int32_t *__restrict__ row_ptr,
-                                                       const int32_t *__restrict__ col_idx,
-                                                       const float *__restrict__ vals,
-                                                       const float *__restrict__ x, float *__restrict__ y,
-                                                       const int32_t *__restrict__ chunk_lb,
-                                                       float *__restrict__ carry,
-                                                       const int32_t *__restrict__ win,
-                                                       const int32_t *__restrict__ list, int kRegion)
+__device__ __forceinline__ void adaptive_body(float *smem, ChunkShared<BLOCK> &sh, int bid, int grid, int64_t rows,
+                                              int64_t nnz, int64_t cols, int chunk0, int nrun,
+                                              const int32_t *__restrict__ row_ptr,
+                                              const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
+                                              const float *__restrict__ x, float *__restrict__ y,
+                                              const int32_t *__restrict__ chunk_lb, float *__restrict__ carry,
+                                              const int32_t *__restrict__ win, const int32_t *__restrict__ list,
+                                              int kRegion)
 {
     constexpr int kChunkT = chunk_of(BLOCK);
     constexpr int kVec = kNnzPerThread / 4;
-    // one dynamic LDS region, used twice: first as the x window (TILED), then -- after the
-    // gathers have landed in registers -- as the product staging buffer.
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ ChunkShared<BLOCK> sh;
 
     const int tid0 = threadIdx.x;
-    Walk wk = first_chunk(PERSIST, blockIdx.x, gridDim.x, nrun);
+    Walk wk = first_chunk(PERSIST, bid, grid, nrun);
     if (wk.c >= wk.end) return;
     if (!PERSIST && list) {  // one-shot launch over a chunk list (the chunks without 16-bit columns)
         wk.c = list[wk.c];
@@ -501,6 +498,19 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
     }
 }
 
+template <int BLOCK, bool TILED, bool PERSIST>
+__global__ __launch_bounds__(BLOCK, waves_per_simd(BLOCK, PERSIST))
+void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun, const int32_t *__restrict__ row_ptr,
+                const int32_t *__restrict__ col_idx, const float *__restrict__ vals, const float *__restrict__ x,
+                float *__restrict__ y, const int32_t *__restrict__ chunk_lb, float *__restrict__ carry,
+                const int32_t *__restrict__ win, const int32_t *__restrict__ list, int kRegion)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ ChunkShared<BLOCK> sh;
+    adaptive_body<BLOCK, TILED, PERSIST>(smem, sh, (int)blockIdx.x, (int)gridDim.x, rows, nnz, cols, chunk0, nrun, row_ptr,
+                                         col_idx, vals, x, y, chunk_lb, carry, win, list, kRegion);
+}
+
 // ---------------------------------------------------------------------------
 // 16-bit columns.  A chunk whose whole column span is staged in LDS never needs absolute columns:
 // the plan stores col - w0 as uint16 (span < 65536), laid out so that each lane's 16 offsets are
@@ -510,26 +520,22 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun,
 using u4 = unsigned __attribute__((ext_vector_type(4)));
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols, int nrun,
-                                                      const int32_t *__restrict__ row_ptr,
-                                                      const uint16_t *__restrict__ col16,
-                                                      const float *__restrict__ vals,
-                                                      const float *__restrict__ x, float *__restrict__ y,
-                                                      const int32_t *__restrict__ chunk_lb,
-                                                      float *__restrict__ carry,
-                                                      const int32_t *__restrict__ win,
-                                                      const int32_t *__restrict__ list, int kRegion)
+__device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh, int bid, int64_t rows, int64_t cols,
+                                             int nrun, const int32_t *__restrict__ row_ptr,
+                                             const uint16_t *__restrict__ col16, const float *__restrict__ vals,
+                                             const float *__restrict__ x, float *__restrict__ y,
+                                             const int32_t *__restrict__ chunk_lb, float *__restrict__ carry,
+                                             const int32_t *__restrict__ win, const int32_t *__restrict__ list,
+                                             int kRegion)
 {
     constexpr int kChunkT = chunk_of(BLOCK);
     constexpr int kVec = kNnzPerThread / 4;
     static_assert(kNnzPerThread == 16, "the col16 lane layout is two 16-byte loads of eight offsets");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ ChunkShared<BLOCK> sh;
 
     const int tid = threadIdx.x;
     // list == nullptr: every chunk has 16-bit columns (the list would be the identity) -- the stream addresses
     // then depend on blockIdx only and the loads leave one dependent global load earlier
-    const int ci = xcd_chunk(blockIdx.x, nrun);
+    const int ci = xcd_chunk(bid, nrun);
     const int c = list ? list[ci] : ci;
     const int64_t base = (int64_t)c * kChunkT;
     const int64_t lim = base + kChunkT;
@@ -595,6 +601,49 @@ __global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols
     }
     __syncthreads();
     reduce_chunk<BLOCK, true>(smem, sh, tid, c, lb0, m, base, lim, row_ptr, y, carry, rb0, re0);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols, int nrun,
+                                                      const int32_t *__restrict__ row_ptr,
+                                                      const uint16_t *__restrict__ col16,
+                                                      const float *__restrict__ vals,
+                                                      const float *__restrict__ x, float *__restrict__ y,
+                                                      const int32_t *__restrict__ chunk_lb,
+                                                      float *__restrict__ carry,
+                                                      const int32_t *__restrict__ win,
+                                                      const int32_t *__restrict__ list, int kRegion)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ ChunkShared<BLOCK> sh;
+    tiled16_body<BLOCK>(smem, sh, (int)blockIdx.x, rows, cols, nrun, row_ptr, col16, vals, x, y, chunk_lb, carry, win, list,
+                        kRegion);
+}
+
+// Both kinds of chunk in ONE launch: workgroups [0, n32) run the 32-bit body over list32 (the slow chunks -- wide
+// spans, outliers gathered from global memory -- start first), the others the 16-bit body over list16.  Two launches
+// would each end with a partly idle chip (power-law rows: 1758 such chunks took 71 us after the 209 us of the rest).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void k_tiled_mixed(int64_t rows, int64_t nnz, int64_t cols, int n32, int n16,
+                                                          const int32_t *__restrict__ row_ptr,
+                                                          const int32_t *__restrict__ col_idx,
+                                                          const uint16_t *__restrict__ col16,
+                                                          const float *__restrict__ vals,
+                                                          const float *__restrict__ x, float *__restrict__ y,
+                                                          const int32_t *__restrict__ chunk_lb,
+                                                          float *__restrict__ carry,
+                                                          const int32_t *__restrict__ win,
+                                                          const int32_t *__restrict__ list32,
+                                                          const int32_t *__restrict__ list16, int kRegion)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ ChunkShared<BLOCK> sh;
+    if ((int)blockIdx.x < n32)
+        adaptive_body<BLOCK, true, false>(smem, sh, (int)blockIdx.x, n32, rows, nnz, cols, 0, n32, row_ptr, col_idx, vals, x,
+                                          y, chunk_lb, carry, win, list32, kRegion);
+    else
+        tiled16_body<BLOCK>(smem, sh, (int)blockIdx.x - n32, rows, cols, n16, row_ptr, col16, vals, x, y, chunk_lb, carry,
+                            win, list16, kRegion);
 }
 
 // plan: 16-bit offsets of every eligible chunk (full chunk, whole span staged, span < 65536), in the
@@ -981,14 +1030,32 @@ static int launch_tiled16(const spmv_csr &h, const ChunkPlan &p, const float *x,
     return check_launch("k_tiled16");
 }
 
+template <int BLOCK>
+static int launch_mixed(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
+{
+    const size_t lds = sizeof(float) * (size_t)p.region;
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
+        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiled_mixed<BLOCK>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.store(true, std::memory_order_release);
+    }
+    const int n32 = p.nchunks - p.n16;
+    hipLaunchKernelGGL((k_tiled_mixed<BLOCK>), dim3(p.nchunks), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols, n32, p.n16,
+                       h.d_row_ptr, h.d_col_idx, p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, p.d_list32,
+                       p.d_list16, p.region);
+    return check_launch("k_tiled_mixed");
+}
+
 template <int BLOCK, bool TILED>
 static int launch_either(bool persist, const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
 {
-    if (TILED && !persist && p.d_col16) {
-        // the chunks with 16-bit columns, then the others through the 32-bit kernel
-        int rc = launch_tiled16<BLOCK>(h, p, x, y, s);
-        if (rc == SPMV_OK) rc = launch_range<BLOCK, TILED, false>(h, p, 0, p.nchunks - p.n16, x, y, s, p.d_list32);
-        return rc;
+    if constexpr (TILED) {
+        if (!persist && p.d_col16) {
+            // every chunk has 16-bit columns: the lean kernel; otherwise both kinds in one launch
+            if (p.n16 == p.nchunks) return launch_tiled16<BLOCK>(h, p, x, y, s);
+            return launch_mixed<BLOCK>(h, p, x, y, s);
+        }
     }
     if (!persist) return launch_range<BLOCK, TILED, false>(h, p, 0, p.nchunks, x, y, s);
     // persistent launch over the full chunks, one-shot launch for a trailing partial chunk
