@@ -57,6 +57,19 @@ def test_dense_conversion_keeps_nan_drops_negative_zero(pkg, oracle, gpu):
     assert list(ci[rp[4]:rp[5]]) == [3, 6]
 
 
+
+@pytest.mark.parametrize("M,N", [(1, 1), (63, 5), (64, 64), (65, 130), (200, 33), (1000, 257), (4097, 66), (3, 5000)])
+def test_device_dense_to_csr_odd_shapes(pkg, oracle, gpu, M, N):
+    """The 64 x 64 tile transposition and the multi-workgroup scan on shapes that are not multiples of anything
+    (ragged last slab, ragged last column tile, a scan just above and below its single-workgroup limit)."""
+    A, _ = pkg.workloads.dense_random(M, N, 0.7, seed=M * 131 + N)
+    m = pkg.capi.CsrMatrix.from_dense_host(A)
+    rp, ci, va = m.download()
+    orp, oci, ova = oracle.csr_from_dense(A)
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+    assert np.array_equal(va.view(np.uint32), ova.view(np.uint32))
+    m.close()
+
 def test_run_host_path(pkg, oracle, gpu):
     g = load_golden("g256x384_10pct")
     A = pkg.capi.CsrMatrix.from_host(g.N, g.M, g.row_ptr, g.col_idx, g.vals)
