@@ -1,5 +1,4 @@
 """Shared fixtures.  `-m "not gpu"` runs here on CPU; `-m gpu` runs on a real MI355X."""
-import os
 import sys
 from pathlib import Path
 

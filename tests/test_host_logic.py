@@ -1,6 +1,5 @@
 """CPU: the host-side logic (workloads, partition), the C-ABI library's exports, the launcher
 surface's symbols, and the loud failure without a GPU.  No compute runs here."""
-import ctypes
 import re
 import subprocess
 from pathlib import Path

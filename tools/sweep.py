@@ -4,7 +4,6 @@ the judged number comes from bench.py.  Usage: python tools/sweep.py [--configs 
 import argparse
 import json
 import sys
-import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent

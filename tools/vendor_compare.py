@@ -60,7 +60,6 @@ class RocSparse:
 
 
 def main():
-    import numpy as np
     import torch
 
     ap = argparse.ArgumentParser()
