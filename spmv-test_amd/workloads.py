@@ -183,6 +183,28 @@ def dense_random(M: int, N: int, zero_fraction: float, seed: int):
     return A, x
 
 
+
+def stencil7(n: int):
+    """Host-built CSR of a 7-point 3-D stencil on n^3 unknowns (columns r, r+-1, r+-n, r+-n^2 where they exist:
+    three narrow clusters of columns 2 n^2 apart -- the structure a single contiguous x window cannot cover).
+    Returns (N, row_ptr int32, col_idx int32 ascending per row, vals float32)."""
+    N = n ** 3
+    r = np.arange(N, dtype=np.int64)
+    i, j, k = r // (n * n), (r // n) % n, r % n
+    offs = [(-n * n, i > 0), (-n, j > 0), (-1, k > 0), (0, np.ones(N, bool)), (1, k < n - 1), (n, j < n - 1), (n * n, i < n - 1)]
+    cnt = sum(m.astype(np.int64) for _, m in offs)
+    rp = np.zeros(N + 1, np.int64)
+    np.cumsum(cnt, out=rp[1:])
+    ci = np.empty(int(rp[-1]), np.int32)
+    va = np.empty(int(rp[-1]), np.float32)
+    pos = rp[:-1].copy()
+    scale = (0.5 + (r * 2654435761 % 1000003).astype(np.float32) / 1000003.0).astype(np.float32)
+    for o, m in offs:            # ascending offsets -> ascending columns inside a row
+        ci[pos[m]] = (r[m] + o).astype(np.int32)
+        va[pos[m]] = (6.0 if o == 0 else -1.0) * scale[m]
+        pos[m] += 1
+    return N, rp.astype(np.int32), ci, va
+
 # ---- the BASELINE.json configs ------------------------------------------------------------------
 Mi = 1 << 20
 CONFIGS = {

@@ -219,6 +219,16 @@ def test_scalar_stays_bit_identical_on_long_rows(pkg, oracle, gpu):
         assert np.array_equal(y, oracle.sgemv_dense(A, x))        # and to the dense SgemvCPU loop itself
         prob.A.close()
 
+
+def test_stencil_matrix_all_variants(pkg, oracle, gpu):
+    """A 7-point 3-D stencil (48^3): three column clusters 2*48^2 apart per row -- no contiguous window covers a
+    chunk, the tiled plan stages nothing and runs the plain kernel; every variant against the oracle."""
+    N, rp, ci, va = pkg.workloads.stencil7(48)
+    x = np.random.Generator(np.random.PCG64(48)).uniform(-1, 1, size=N).astype(np.float32)
+    prob = DeviceProblem(pkg, gpu, N, N, rp, ci, va, x)
+    _check_all_variants(pkg, oracle, prob, "stencil7(48)")
+    prob.A.close()
+
 def test_results_are_deterministic_run_to_run(pkg, oracle, gpu):
     w = pkg.workloads.config("c3", scale=1 / 32)
     prob = synth_problem(pkg, oracle, gpu, w)
