@@ -313,9 +313,9 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
     else if (!p) snprintf(buf, (size_t)n, "no plan");
     else if (!p->block) snprintf(buf, (size_t)n, "not planned");
     else
-        snprintf(buf, (size_t)n, "block=%d region=%d maxpass=%d chunks=%d staged_single=%d staged_full=%d col16_chunks=%d spanning_rows=%d persist=%d",
-                 p->block, p->region, p->maxpass, p->nchunks, p->staged_single, p->staged_full, p->n16, p->spanning_rows,
-                 p->persist ? 1 : 0);
+        snprintf(buf, (size_t)n, "block=%d region=%d maxpass=%d chunks=%d staged_single=%d staged_full=%d col16_chunks=%d block_list_chunks=%d spanning_rows=%d persist=%d",
+                 p->block, p->region, p->maxpass, p->nchunks, p->staged_single, p->staged_full, p->n16, p->nblk_chunks,
+                 p->spanning_rows, p->persist ? 1 : 0);
     return SPMV_OK;
 }
 

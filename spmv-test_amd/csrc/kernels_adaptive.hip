@@ -29,6 +29,7 @@
 //     covers the windows of >= 90 % of the chunks, and a chunk whose window does not fit
 //     gathers from global memory.
 #include <atomic>
+#include <climits>
 #include <cstdlib>
 #include "spmv_internal.hpp"
 
@@ -94,7 +95,10 @@ __global__ void k_plan_chunks(int64_t rows, int nchunks, int chunk, const int32_
 // staged completely (any number of passes).
 constexpr int kOutsideBit = 1 << 30;
 constexpr int kCol16Bit = 1 << 29;   // the chunk's columns also exist as 16-bit offsets from w0 (plan.d_col16)
-constexpr int kLenMask = kCol16Bit - 1;
+constexpr int kBlockBit = 1 << 28;   // ... as 16-bit indices into a LIST of staged 1024-column blocks (plan.d_blk)
+constexpr int kLenMask = kBlockBit - 1;
+constexpr int kBlkCols = 1024;       // columns per staged block
+constexpr int kBlkMax = 64;          // blocks per chunk: 64 * 1024 staged floats is what a 16-bit index reaches
 
 __global__ __launch_bounds__(256) void k_plan_windows(int64_t nnz, int64_t cols, int nchunks, int chunk,
                                                       const int32_t *__restrict__ col_idx,
@@ -368,6 +372,28 @@ __device__ __forceinline__ void stage_slice(const float *__restrict__ x, int64_t
 // The body of k_adaptive for workgroup `bid` of `grid` (a device function so that k_tiled_mixed can run it beside
 // the 16-bit body in one launch).  smem: one dynamic LDS region, used twice: first as the x window (TILED), then
 // -- after the gathers have landed in registers -- as the product staging buffer.
+// A slice of a chunk's BLOCK LIST, global -> LDS: block ids[b] (1024 columns of x) lands at smem + 1024 b.  One wave
+// per block and trip, four 1-KiB LDS-DMA pieces each.  The last block of x is copied element by element.
+template <int BLOCK>
+__device__ __forceinline__ void stage_blocks(const float *__restrict__ x, const int32_t *__restrict__ ids, int nb,
+                                             int64_t cols, float *smem, int tid)
+{
+    const int lane = tid & (kWave - 1);
+    for (int b = __builtin_amdgcn_readfirstlane(tid >> 6); b < nb; b += BLOCK / kWave) {   // wave-uniform: scalar ids
+        const int64_t g = (int64_t)ids[b] * kBlkCols;
+        float *dst = smem + b * kBlkCols;
+        if (g + kBlkCols + 3 < cols) {
+            const float *src = x + g + lane * 4;
+#pragma unroll 1
+            for (int q = 0; q < kBlkCols / (kWave * 4); ++q)
+                __builtin_amdgcn_global_load_lds(src + q * kWave * 4, dst + (q * kWave + lane) * 4, 16, 0, 0);
+        } else {
+            for (int i = lane; i < kBlkCols; i += kWave)
+                if (g + i < cols) dst[i] = x[g + i];
+        }
+    }
+}
+
 template <int BLOCK, bool TILED, bool PERSIST>
 __device__ __forceinline__ void adaptive_body(float *smem, ChunkShared<BLOCK> &sh, int bid, int grid, int64_t rows,
                                               int64_t nnz, int64_t cols, int chunk0, int nrun,
@@ -519,14 +545,14 @@ void k_adaptive(int64_t rows, int64_t nnz, int64_t cols, int chunk0, int nrun, c
 // (outliers gathered from global memory, the ragged last chunk) go through k_adaptive.
 using u4 = unsigned __attribute__((ext_vector_type(4)));
 
-template <int BLOCK>
+template <int BLOCK, bool BLOCKS>
 __device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh, int bid, int64_t rows, int64_t cols,
                                              int nrun, const int32_t *__restrict__ row_ptr,
                                              const uint16_t *__restrict__ col16, const float *__restrict__ vals,
                                              const float *__restrict__ x, float *__restrict__ y,
                                              const int32_t *__restrict__ chunk_lb, float *__restrict__ carry,
                                              const int32_t *__restrict__ win, const int32_t *__restrict__ list,
-                                             int kRegion)
+                                             int kRegionArg, const int32_t *__restrict__ blk)
 {
     constexpr int kChunkT = chunk_of(BLOCK);
     constexpr int kVec = kNnzPerThread / 4;
@@ -543,7 +569,12 @@ __device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh
     const int lb0 = chunk_lb[c], lb1 = chunk_lb[c + 1];
     const int m = lb1 - lb0;
     const int w0 = win[2 * c];
-    const int wlen = win[2 * c + 1] & kLenMask;
+    const int wl = win[2 * c + 1];
+    const int wlen = wl & kLenMask;
+    // BLOCKS: this chunk's x is a LIST of 1024-column blocks (its columns sit in a few clusters far apart); the
+    // 16-bit offsets index the concatenation of the staged blocks, everything after the staging is the same
+    const bool by_blocks = BLOCKS && (wl & kBlockBit);
+    const int kRegion = by_blocks ? (kRegionArg / kBlkCols) * kBlkCols : kRegionArg;
 
     // ---- stream: 2 x 16 B of offsets + 4 x 16 B of values per lane, non-temporal
     u4 raw[2];
@@ -574,7 +605,8 @@ __device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh
     for (int off = 0; off < wlen; off += kRegion) {
         const int len = (wlen - off) < kRegion ? (wlen - off) : kRegion;
         const int64_t g0 = (int64_t)w0 + off;
-        stage_slice<BLOCK, true>(x, g0, len, cols, smem, tid);
+        if (by_blocks) stage_blocks<BLOCK>(x, blk + (int64_t)c * kBlkMax + off / kBlkCols, len / kBlkCols, cols, smem, tid);
+        else stage_slice<BLOCK, true>(x, g0, len, cols, smem, tid);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kVec; ++j)
@@ -603,7 +635,7 @@ __device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh
     reduce_chunk<BLOCK, true>(smem, sh, tid, c, lb0, m, base, lim, row_ptr, y, carry, rb0, re0);
 }
 
-template <int BLOCK>
+template <int BLOCK, bool BLOCKS>
 __global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols, int nrun,
                                                       const int32_t *__restrict__ row_ptr,
                                                       const uint16_t *__restrict__ col16,
@@ -612,18 +644,19 @@ __global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols
                                                       const int32_t *__restrict__ chunk_lb,
                                                       float *__restrict__ carry,
                                                       const int32_t *__restrict__ win,
-                                                      const int32_t *__restrict__ list, int kRegion)
+                                                      const int32_t *__restrict__ list, int kRegion,
+                                                      const int32_t *__restrict__ blk)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ ChunkShared<BLOCK> sh;
-    tiled16_body<BLOCK>(smem, sh, (int)blockIdx.x, rows, cols, nrun, row_ptr, col16, vals, x, y, chunk_lb, carry, win, list,
-                        kRegion);
+    tiled16_body<BLOCK, BLOCKS>(smem, sh, (int)blockIdx.x, rows, cols, nrun, row_ptr, col16, vals, x, y, chunk_lb, carry, win,
+                                list, kRegion, blk);
 }
 
 // Both kinds of chunk in ONE launch: workgroups [0, n32) run the 32-bit body over list32 (the slow chunks -- wide
 // spans, outliers gathered from global memory -- start first), the others the 16-bit body over list16.  Two launches
 // would each end with a partly idle chip (power-law rows: 1758 such chunks took 71 us after the 209 us of the rest).
-template <int BLOCK>
+template <int BLOCK, bool BLOCKS>
 __global__ __launch_bounds__(BLOCK, 8) void k_tiled_mixed(int64_t rows, int64_t nnz, int64_t cols, int n32, int n16,
                                                           const int32_t *__restrict__ row_ptr,
                                                           const int32_t *__restrict__ col_idx,
@@ -634,7 +667,8 @@ __global__ __launch_bounds__(BLOCK, 8) void k_tiled_mixed(int64_t rows, int64_t 
                                                           float *__restrict__ carry,
                                                           const int32_t *__restrict__ win,
                                                           const int32_t *__restrict__ list32,
-                                                          const int32_t *__restrict__ list16, int kRegion)
+                                                          const int32_t *__restrict__ list16, int kRegion,
+                                                          const int32_t *__restrict__ blk)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ ChunkShared<BLOCK> sh;
@@ -642,8 +676,8 @@ __global__ __launch_bounds__(BLOCK, 8) void k_tiled_mixed(int64_t rows, int64_t 
         adaptive_body<BLOCK, true, false>(smem, sh, (int)blockIdx.x, n32, rows, nnz, cols, 0, n32, row_ptr, col_idx, vals, x,
                                           y, chunk_lb, carry, win, list32, kRegion);
     else
-        tiled16_body<BLOCK>(smem, sh, (int)blockIdx.x - n32, rows, cols, n16, row_ptr, col16, vals, x, y, chunk_lb, carry,
-                            win, list16, kRegion);
+        tiled16_body<BLOCK, BLOCKS>(smem, sh, (int)blockIdx.x - n32, rows, cols, n16, row_ptr, col16, vals, x, y, chunk_lb,
+                                    carry, win, list16, kRegion, blk);
 }
 
 // plan: 16-bit offsets of every eligible chunk (full chunk, whole span staged, span < 65536), in the
@@ -651,21 +685,103 @@ __global__ __launch_bounds__(BLOCK, 8) void k_tiled_mixed(int64_t rows, int64_t 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t *__restrict__ col_idx,
                                                       int32_t *__restrict__ win, uint16_t *__restrict__ col16,
-                                                      int32_t *__restrict__ flags)
+                                                      int32_t *__restrict__ flags, int region, int maxpass,
+                                                      int32_t *__restrict__ blk, int32_t *__restrict__ blk_chunks)
 {
     constexpr int kChunkT = chunk_of(BLOCK);
+    __shared__ int s_min, s_max, s_total;
+    __shared__ unsigned bits[BLOCK];   // occupancy of the 1024-column blocks [s_min, s_min + 32 BLOCK)
+    __shared__ int pref[BLOCK];        // occupied blocks before word t
     const int c = blockIdx.x, tid = threadIdx.x;
     const int64_t base = (int64_t)c * kChunkT;
     const int wl = win[2 * c + 1];
     const int wlen = wl & kLenMask;
-    const bool ok = (nnz - base) >= kChunkT && wlen > 0 && wlen < 65536 && !(wl & kOutsideBit);
-    __syncthreads();  // everyone has read win before lane 0 rewrites it
-    if (tid == 0) {
-        flags[c] = ok ? 1 : 0;
-        if (ok) win[2 * c + 1] = wl | kCol16Bit;
-    }
-    if (!ok) return;
+    const bool full_chunk = (nnz - base) >= kChunkT;
+    const bool contiguous = full_chunk && wlen > 0 && wlen < 65536 && !(wl & kOutsideBit);
     const int w0 = win[2 * c];
+    if (tid == 0) { s_min = INT_MAX; s_max = -1; }
+    __syncthreads();  // (also: everyone has read win before lane 0 rewrites it)
+
+    // ---- a LIST of 1024-column blocks instead of one span?  Tried where the span is not staged in one pass (or not
+    //      at all): columns in a few clusters far apart (3-D stencils: r, r+-n, r+-n^2) occupy a handful of blocks.
+    bool by_blocks = false;
+    if (full_chunk && blk && !(contiguous && wlen <= region)) {   // chunk-uniform
+        int bmin = INT_MAX, bmax = -1;
+        for (int i = tid; i < kChunkT; i += BLOCK) {
+            const int b = col_idx[base + i] >> 10;
+            bmin = b < bmin ? b : bmin;
+            bmax = b > bmax ? b : bmax;
+        }
+        atomicMin(&s_min, bmin);
+        atomicMax(&s_max, bmax);
+        bits[tid] = 0u;
+        __syncthreads();
+        const int lo = s_min;
+        if (s_max - lo < 32 * BLOCK) {   // chunk-uniform
+            for (int i = tid; i < kChunkT; i += BLOCK) {
+                const int d = (col_idx[base + i] >> 10) - lo;
+                atomicOr(&bits[d >> 5], 1u << (d & 31));
+            }
+            __syncthreads();
+            const int mine = __popc(bits[tid]);
+            pref[tid] = mine;
+            __syncthreads();
+            for (int o = 1; o < BLOCK; o <<= 1) {
+                const int v = tid >= o ? pref[tid - o] : 0;
+                __syncthreads();
+                pref[tid] += v;
+                __syncthreads();
+            }
+            if (tid == BLOCK - 1) s_total = pref[tid];
+            const int before = pref[tid] - mine;
+            __syncthreads();
+            pref[tid] = before;
+            __syncthreads();
+            const int total = s_total;
+            const int cap = (region / kBlkCols) * kBlkCols;
+            by_blocks = total <= kBlkMax && (int64_t)total * kBlkCols <= (int64_t)maxpass * cap &&
+                        (!contiguous || total * kBlkCols < wlen);
+            if (by_blocks) {
+                unsigned w = bits[tid];
+                int slot = before;
+                while (w) {
+                    const int j = __ffs(w) - 1;
+                    w &= w - 1;
+                    blk[(int64_t)c * kBlkMax + slot++] = lo + tid * 32 + j;
+                }
+                if (tid == 0) {
+                    flags[c] = 1;
+                    win[2 * c + 1] = (total * kBlkCols) | kCol16Bit | kBlockBit;
+                    atomicAdd(blk_chunks, 1);
+                }
+                u4 *out = reinterpret_cast<u4 *>(col16 + base);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    unsigned v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int jj = 2 * k + (e >> 2), q = e & 3;
+                        const int col = col_idx[base + (jj * BLOCK + tid) * 4 + q];
+                        const int d = (col >> 10) - lo;
+                        const int sl = pref[d >> 5] + __popc(bits[d >> 5] & ((1u << (d & 31)) - 1u));
+                        v[e] = (unsigned)(sl * kBlkCols + (col & (kBlkCols - 1)));
+                    }
+                    u4 wv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wv[i] = v[2 * i] | (v[2 * i + 1] << 16);
+                    out[k * BLOCK + tid] = wv;
+                }
+            }
+        }
+    }
+    if (by_blocks) return;
+
+    // ---- one contiguous span: offsets from its first column
+    if (tid == 0) {
+        flags[c] = contiguous ? 1 : 0;
+        if (contiguous) win[2 * c + 1] = wl | kCol16Bit;
+    }
+    if (!contiguous) return;
     u4 *out = reinterpret_cast<u4 *>(col16 + base);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -680,6 +796,14 @@ __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t
         for (int i = 0; i < 4; ++i) w[i] = v[2 * i] | (v[2 * i + 1] << 16);
         out[k * BLOCK + tid] = w;
     }
+}
+
+// plan: the 16-bit copy was dropped -- chunks that had switched to a block list go back to "nothing staged"
+// (their win[] no longer describes a contiguous span; the 32-bit kernel then gathers them from global memory)
+__global__ void k_plan_unblock(int nchunks, int32_t *__restrict__ win)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nchunks && (win[2 * c + 1] & kBlockBit)) win[2 * c + 1] = 0;
 }
 
 // plan: chunk lists from the exclusive scan of flags: list16[pos[c]] = c, list32[c - pos[c]] = c
@@ -736,6 +860,7 @@ static void free_plan(ChunkPlan &p)
     if (p.d_col16) (void)hipFree(p.d_col16);
     if (p.d_list16) (void)hipFree(p.d_list16);
     if (p.d_list32) (void)hipFree(p.d_list32);
+    if (p.d_blk) (void)hipFree(p.d_blk);
     p = ChunkPlan();
 }
 
@@ -799,10 +924,10 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
 }
 
 template <int BLOCK>
-static int launch_plan_col16(const spmv_csr &h, ChunkPlan &p, int32_t *d_flags, hipStream_t s)
+static int launch_plan_col16(const spmv_csr &h, ChunkPlan &p, int32_t *d_flags, int32_t *d_blk_chunks, hipStream_t s)
 {
     hipLaunchKernelGGL((k_plan_col16<BLOCK>), dim3(p.nchunks), dim3(BLOCK), 0, s, h.nnz, h.d_col_idx, p.d_win, p.d_col16,
-                       d_flags);
+                       d_flags, p.region, p.maxpass, p.d_blk, d_blk_chunks);
     return check_launch("k_plan_col16");
 }
 
@@ -821,25 +946,42 @@ static int build_col16(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
     SPMV_HIP_TRY(hipMalloc((void **)&p.d_col16, sizeof(uint16_t) * chunk * (size_t)p.nchunks));
     SPMV_HIP_TRY(hipMalloc((void **)&p.d_list16, sizeof(int32_t) * (size_t)p.nchunks));
     SPMV_HIP_TRY(hipMalloc((void **)&p.d_list32, sizeof(int32_t) * (size_t)p.nchunks));
+    // block lists (kBlkMax ids per chunk): SPMV_BLOCKS=0 keeps contiguous windows only
+    bool want_blocks = true;
+    if (const char *e = getenv("SPMV_BLOCKS")) want_blocks = atoi(e) != 0;
+    DevPtr<int32_t> nblk;
+    SPMV_HIP_TRY(nblk.alloc(1));
+    SPMV_HIP_TRY(hipMemsetAsync(nblk.p, 0, sizeof(int32_t), s));
+    if (want_blocks) SPMV_HIP_TRY(hipMalloc((void **)&p.d_blk, sizeof(int32_t) * (size_t)kBlkMax * (size_t)p.nchunks));
     int rc;
-    if (p.block == 256) rc = launch_plan_col16<256>(h, p, flags.p, s);
-    else if (p.block == 512) rc = launch_plan_col16<512>(h, p, flags.p, s);
-    else rc = launch_plan_col16<1024>(h, p, flags.p, s);
+    if (p.block == 256) rc = launch_plan_col16<256>(h, p, flags.p, nblk.p, s);
+    else if (p.block == 512) rc = launch_plan_col16<512>(h, p, flags.p, nblk.p, s);
+    else rc = launch_plan_col16<1024>(h, p, flags.p, nblk.p, s);
     if (rc) return rc;
     SPMV_HIP_TRY(hipMemcpyAsync(pos.p, flags.p, sizeof(int32_t) * (size_t)p.nchunks, hipMemcpyDeviceToDevice, s));
     if ((rc = exclusive_scan_i32(pos.p, p.nchunks, total.p, s))) return rc;
     hipLaunchKernelGGL(k_plan_lists, dim3((p.nchunks + 255) / 256), dim3(256), 0, s, p.nchunks, flags.p, pos.p, p.d_list16,
                        p.d_list32);
     if ((rc = check_launch("k_plan_lists"))) return rc;
-    int32_t n16 = 0;
+    int32_t n16 = 0, nb = 0;
     SPMV_HIP_TRY(hipMemcpyAsync(&n16, total.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipMemcpyAsync(&nb, nblk.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SPMV_HIP_TRY(hipStreamSynchronize(s));
     p.n16 = n16;
-    if (2 * (int64_t)n16 < p.nchunks) {  // too few eligible chunks to pay for a second launch: 32-bit path
+    p.nblk_chunks = nb;
+    if (nb == 0 && p.d_blk) { (void)hipFree(p.d_blk); p.d_blk = nullptr; }
+    if (2 * (int64_t)n16 < p.nchunks) {  // too few eligible chunks to pay for the 2-byte copy: 32-bit path
         p.n16 = 0;
+        if (p.nblk_chunks > 0) {
+            hipLaunchKernelGGL(k_plan_unblock, dim3((p.nchunks + 255) / 256), dim3(256), 0, s, p.nchunks, p.d_win);
+            if ((rc = check_launch("k_plan_unblock"))) return rc;
+            SPMV_HIP_TRY(hipStreamSynchronize(s));
+        }
+        p.nblk_chunks = 0;
         (void)hipFree(p.d_col16); p.d_col16 = nullptr;
         (void)hipFree(p.d_list16); p.d_list16 = nullptr;
         (void)hipFree(p.d_list32); p.d_list32 = nullptr;
+        if (p.d_blk) { (void)hipFree(p.d_blk); p.d_blk = nullptr; }
     }
     return SPMV_OK;
 }
@@ -904,7 +1046,14 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
             if (rc0) return rc0;
             if (h.plan_tiled.nchunks == 0 || full > 0) { any = true; break; }
         }
-        if (!any) return SPMV_OK;   // the (256, 2) plan built last stands; no 16-bit copy (nothing is staged)
+        if (!any) {
+            // no contiguous span fits -- but a few column clusters far apart (a big 3-D stencil) fit as block lists
+            int rc0 = build_plan(h, 512, 8, s, h.plan_tiled, nullptr, nullptr);
+            if (rc0 == SPMV_OK) rc0 = build_col16(h, h.plan_tiled, s);
+            if (rc0) return rc0;
+            any = h.plan_tiled.nblk_chunks > 0;
+        }
+        if (!any) return build_plan(h, 256, 2, s, h.plan_tiled, nullptr, nullptr);   // plain kernel, no 16-bit copy
     }
     DevPtr<float> xt, yt;
     SPMV_HIP_TRY(xt.alloc((size_t)h.cols));
@@ -1013,38 +1162,51 @@ static int launch_range(const spmv_csr &h, const ChunkPlan &p, int chunk0, int n
     return check_launch("k_adaptive");
 }
 
+template <int BLOCK, bool BLOCKS>
+static int launch_tiled16_t(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
+{
+    const size_t lds = sizeof(float) * (size_t)p.region;
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
+        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiled16<BLOCK, BLOCKS>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_tiled16<BLOCK, BLOCKS>), dim3(p.n16), dim3(BLOCK), lds, s, h.rows, h.cols, p.n16, h.d_row_ptr,
+                       p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win,
+                       p.n16 == p.nchunks ? (const int32_t *)nullptr : p.d_list16, p.region, p.d_blk);
+    return check_launch("k_tiled16");
+}
+
 template <int BLOCK>
 static int launch_tiled16(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
 {
     if (p.n16 <= 0) return SPMV_OK;
+    // the block-list staging is compiled in only for plans that have such chunks
+    return p.nblk_chunks > 0 ? launch_tiled16_t<BLOCK, true>(h, p, x, y, s) : launch_tiled16_t<BLOCK, false>(h, p, x, y, s);
+}
+
+template <int BLOCK, bool BLOCKS>
+static int launch_mixed_t(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
+{
     const size_t lds = sizeof(float) * (size_t)p.region;
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
-        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiled16<BLOCK>),
+        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiled_mixed<BLOCK, BLOCKS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_tiled16<BLOCK>), dim3(p.n16), dim3(BLOCK), lds, s, h.rows, h.cols, p.n16, h.d_row_ptr,
-                       p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win,
-                       p.n16 == p.nchunks ? (const int32_t *)nullptr : p.d_list16, p.region);
-    return check_launch("k_tiled16");
+    const int n32 = p.nchunks - p.n16;
+    hipLaunchKernelGGL((k_tiled_mixed<BLOCK, BLOCKS>), dim3(p.nchunks), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols, n32,
+                       p.n16, h.d_row_ptr, h.d_col_idx, p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, p.d_list32,
+                       p.d_list16, p.region, p.d_blk);
+    return check_launch("k_tiled_mixed");
 }
 
 template <int BLOCK>
 static int launch_mixed(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
 {
-    const size_t lds = sizeof(float) * (size_t)p.region;
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
-        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiled_mixed<BLOCK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.store(true, std::memory_order_release);
-    }
-    const int n32 = p.nchunks - p.n16;
-    hipLaunchKernelGGL((k_tiled_mixed<BLOCK>), dim3(p.nchunks), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols, n32, p.n16,
-                       h.d_row_ptr, h.d_col_idx, p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, p.d_list32,
-                       p.d_list16, p.region);
-    return check_launch("k_tiled_mixed");
+    return p.nblk_chunks > 0 ? launch_mixed_t<BLOCK, true>(h, p, x, y, s) : launch_mixed_t<BLOCK, false>(h, p, x, y, s);
 }
 
 template <int BLOCK, bool TILED>

@@ -58,6 +58,8 @@ struct ChunkPlan {
     int32_t *d_list16 = nullptr;   // [n16] chunks run by k_tiled16
     int32_t *d_list32 = nullptr;   // [nchunks - n16] the others, run by k_adaptive
     int n16 = 0;
+    int32_t *d_blk = nullptr;      // [64 * nchunks] ids of the staged 1024-column blocks of the chunks that use a list
+    int nblk_chunks = 0;           // how many chunks do
     int maxpass = 0;
     int spanning_rows = 0;         // rows that continue past their owner chunk (0: no fix-up launch)
     int region = 0;                // floats of the dynamic LDS region (x slice, then products)

@@ -101,6 +101,31 @@ def test_panel_refuses_more_columns_than_its_format_holds(pkg, gpu):
     A.plan(capi.TILED)            # the other variants take it
     A.close()
 
+
+def test_block_list_staging_on_a_stencil(pkg, oracle, gpu, monkeypatch):
+    """Columns in three clusters 2*96^2 apart (7-point stencil on 96^3): no contiguous window is staged in one pass,
+    the plan switches those chunks to a LIST of 1024-column blocks (16-bit indices into the staged blocks) and the
+    result still matches; with the 16-bit copy refused the same chunks fall back cleanly."""
+    N, rp, ci, va = pkg.workloads.stencil7(96)
+    x = np.random.Generator(np.random.PCG64(96)).uniform(-1, 1, size=N).astype(np.float32)
+    y64, mag = oracle.spmv_f64(rp, ci, va, x)
+    from _util import DeviceProblem
+    for blk, passes in (("512", "8"), ("1024", "6"), ("256", "2")):
+        monkeypatch.setenv("SPMV_TILED_BLOCK", blk)
+        monkeypatch.setenv("SPMV_MAXPASS", passes)
+        prob = DeviceProblem(pkg, gpu, N, N, rp, ci, va, x)
+        y = prob.run(pkg.capi.TILED)
+        desc = prob.A.plan_describe(pkg.capi.TILED)
+        assert_close_to_oracle(y, y64, mag, f"stencil blocks {blk}/{passes}: {desc}")
+        if blk != "256":
+            assert int(desc.split("block_list_chunks=")[1].split()[0]) > 0, desc
+        prob.A.close()
+    monkeypatch.setenv("SPMV_BLOCKS", "0")
+    prob = DeviceProblem(pkg, gpu, N, N, rp, ci, va, x)
+    assert_close_to_oracle(prob.run(pkg.capi.TILED), y64, mag, "stencil, block lists off")
+    assert "block_list_chunks=0" in prob.A.plan_describe(pkg.capi.TILED)
+    prob.A.close()
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
