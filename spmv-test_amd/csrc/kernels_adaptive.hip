@@ -95,10 +95,14 @@ __global__ void k_plan_chunks(int64_t rows, int nchunks, int chunk, const int32_
 // staged completely (any number of passes).
 constexpr int kOutsideBit = 1 << 30;
 constexpr int kCol16Bit = 1 << 29;   // the chunk's columns also exist as 16-bit offsets from w0 (plan.d_col16)
-constexpr int kBlockBit = 1 << 28;   // ... as 16-bit indices into a LIST of staged 1024-column blocks (plan.d_blk)
+constexpr int kBlockBit = 1 << 28;   // ... as 16-bit indices into a LIST of staged 256-column blocks (plan.d_blk)
 constexpr int kLenMask = kBlockBit - 1;
-constexpr int kBlkCols = 1024;       // columns per staged block
-constexpr int kBlkMax = 64;          // blocks per chunk: 64 * 1024 staged floats is what a 16-bit index reaches
+#ifndef SPMV_T_BLKBITS
+#define SPMV_T_BLKBITS 8
+#endif
+constexpr int kBlkBits = SPMV_T_BLKBITS;
+constexpr int kBlkCols = 1 << kBlkBits;      // columns per staged block (256: one 1-KiB LDS-DMA piece per wave)
+constexpr int kBlkMax = 65536 / kBlkCols;    // blocks per chunk: 65 536 staged floats is what a 16-bit index reaches
 
 __global__ __launch_bounds__(256) void k_plan_windows(int64_t nnz, int64_t cols, int nchunks, int chunk,
                                                       const int32_t *__restrict__ col_idx,
@@ -372,8 +376,8 @@ __device__ __forceinline__ void stage_slice(const float *__restrict__ x, int64_t
 // The body of k_adaptive for workgroup `bid` of `grid` (a device function so that k_tiled_mixed can run it beside
 // the 16-bit body in one launch).  smem: one dynamic LDS region, used twice: first as the x window (TILED), then
 // -- after the gathers have landed in registers -- as the product staging buffer.
-// A slice of a chunk's BLOCK LIST, global -> LDS: block ids[b] (1024 columns of x) lands at smem + 1024 b.  One wave
-// per block and trip, four 1-KiB LDS-DMA pieces each.  The last block of x is copied element by element.
+// A slice of a chunk's BLOCK LIST, global -> LDS: block ids[b] (kBlkCols columns of x) lands at smem + kBlkCols b.  One wave
+// per block and trip, one 1-KiB LDS-DMA piece each.  The last block of x is copied element by element.
 template <int BLOCK>
 __device__ __forceinline__ void stage_blocks(const float *__restrict__ x, const int32_t *__restrict__ ids, int nb,
                                              int64_t cols, float *smem, int tid)
@@ -385,7 +389,7 @@ __device__ __forceinline__ void stage_blocks(const float *__restrict__ x, const 
         if (g + kBlkCols + 3 < cols) {
             const float *src = x + g + lane * 4;
 #pragma unroll 1
-            for (int q = 0; q < kBlkCols / (kWave * 4); ++q)
+            for (int q = 0; q < kBlkCols / (kWave * 4); ++q)   // one trip at 256 columns per block
                 __builtin_amdgcn_global_load_lds(src + q * kWave * 4, dst + (q * kWave + lane) * 4, 16, 0, 0);
         } else {
             for (int i = lane; i < kBlkCols; i += kWave)
@@ -571,7 +575,7 @@ __device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh
     const int w0 = win[2 * c];
     const int wl = win[2 * c + 1];
     const int wlen = wl & kLenMask;
-    // BLOCKS: this chunk's x is a LIST of 1024-column blocks (its columns sit in a few clusters far apart); the
+    // BLOCKS: this chunk's x is a LIST of 256-column blocks (its columns sit in a few clusters far apart); the
     // 16-bit offsets index the concatenation of the staged blocks, everything after the staging is the same
     const bool by_blocks = BLOCKS && (wl & kBlockBit);
     const int kRegion = by_blocks ? (kRegionArg / kBlkCols) * kBlkCols : kRegionArg;
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t
 {
     constexpr int kChunkT = chunk_of(BLOCK);
     __shared__ int s_min, s_max, s_total;
-    __shared__ unsigned bits[BLOCK];   // occupancy of the 1024-column blocks [s_min, s_min + 32 BLOCK)
+    __shared__ unsigned bits[BLOCK];   // occupancy of the 256-column blocks [s_min, s_min + 32 BLOCK)
     __shared__ int pref[BLOCK];        // occupied blocks before word t
     const int c = blockIdx.x, tid = threadIdx.x;
     const int64_t base = (int64_t)c * kChunkT;
@@ -702,13 +706,13 @@ __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t
     if (tid == 0) { s_min = INT_MAX; s_max = -1; }
     __syncthreads();  // (also: everyone has read win before lane 0 rewrites it)
 
-    // ---- a LIST of 1024-column blocks instead of one span?  Tried where the span is not staged in one pass (or not
+    // ---- a LIST of 256-column blocks instead of one span?  Tried where the span is not staged in one pass (or not
     //      at all): columns in a few clusters far apart (3-D stencils: r, r+-n, r+-n^2) occupy a handful of blocks.
     bool by_blocks = false;
     if (full_chunk && blk && !(contiguous && wlen <= region)) {   // chunk-uniform
         int bmin = INT_MAX, bmax = -1;
         for (int i = tid; i < kChunkT; i += BLOCK) {
-            const int b = col_idx[base + i] >> 10;
+            const int b = col_idx[base + i] >> kBlkBits;
             bmin = b < bmin ? b : bmin;
             bmax = b > bmax ? b : bmax;
         }
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t
         const int lo = s_min;
         if (s_max - lo < 32 * BLOCK) {   // chunk-uniform
             for (int i = tid; i < kChunkT; i += BLOCK) {
-                const int d = (col_idx[base + i] >> 10) - lo;
+                const int d = (col_idx[base + i] >> kBlkBits) - lo;
                 atomicOr(&bits[d >> 5], 1u << (d & 31));
             }
             __syncthreads();
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t
                     for (int e = 0; e < 8; ++e) {
                         const int jj = 2 * k + (e >> 2), q = e & 3;
                         const int col = col_idx[base + (jj * BLOCK + tid) * 4 + q];
-                        const int d = (col >> 10) - lo;
+                        const int d = (col >> kBlkBits) - lo;
                         const int sl = pref[d >> 5] + __popc(bits[d >> 5] & ((1u << (d & 31)) - 1u));
                         v[e] = (unsigned)(sl * kBlkCols + (col & (kBlkCols - 1)));
                     }

@@ -104,7 +104,7 @@ def test_panel_refuses_more_columns_than_its_format_holds(pkg, gpu):
 
 def test_block_list_staging_on_a_stencil(pkg, oracle, gpu, monkeypatch):
     """Columns in three clusters 2*96^2 apart (7-point stencil on 96^3): no contiguous window is staged in one pass,
-    the plan switches those chunks to a LIST of 1024-column blocks (16-bit indices into the staged blocks) and the
+    the plan switches those chunks to a LIST of 256-column blocks (16-bit indices into the staged blocks) and the
     result still matches; with the 16-bit copy refused the same chunks fall back cleanly."""
     N, rp, ci, va = pkg.workloads.stencil7(96)
     x = np.random.Generator(np.random.PCG64(96)).uniform(-1, 1, size=N).astype(np.float32)
