@@ -690,7 +690,8 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t *__restrict__ col_idx,
                                                       int32_t *__restrict__ win, uint16_t *__restrict__ col16,
                                                       int32_t *__restrict__ flags, int region, int maxpass,
-                                                      int32_t *__restrict__ blk, int32_t *__restrict__ blk_chunks)
+                                                      int32_t *__restrict__ blk, int32_t *__restrict__ blk_chunks,
+                                                      int dry)
 {
     constexpr int kChunkT = chunk_of(BLOCK);
     __shared__ int s_min, s_max, s_total;
@@ -743,8 +744,13 @@ __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t
             __syncthreads();
             const int total = s_total;
             const int cap = (region / kBlkCols) * kBlkCols;
-            by_blocks = total <= kBlkMax && (int64_t)total * kBlkCols <= (int64_t)maxpass * cap &&
-                        (!contiguous || total * kBlkCols < wlen);
+            // worth it only when the blocks fit ONE pass (a multi-pass list is no better than a multi-pass span)
+            by_blocks = total <= kBlkMax && total * kBlkCols <= cap && (!contiguous || total * kBlkCols < wlen);
+            (void)maxpass;
+            if (by_blocks && dry) {   // counting run: how many chunks would switch (the plan decides, see build_col16)
+                if (tid == 0) atomicAdd(blk_chunks, 1);
+                return;
+            }
             if (by_blocks) {
                 unsigned w = bits[tid];
                 int slot = before;
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t
             }
         }
     }
-    if (by_blocks) return;
+    if (by_blocks || dry) return;
 
     // ---- one contiguous span: offsets from its first column
     if (tid == 0) {
@@ -928,10 +934,11 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
 }
 
 template <int BLOCK>
-static int launch_plan_col16(const spmv_csr &h, ChunkPlan &p, int32_t *d_flags, int32_t *d_blk_chunks, hipStream_t s)
+static int launch_plan_col16(const spmv_csr &h, ChunkPlan &p, int32_t *d_flags, int32_t *d_blk_chunks, const int32_t *d_blk_arg,
+                             int dry, hipStream_t s)
 {
     hipLaunchKernelGGL((k_plan_col16<BLOCK>), dim3(p.nchunks), dim3(BLOCK), 0, s, h.nnz, h.d_col_idx, p.d_win, p.d_col16,
-                       d_flags, p.region, p.maxpass, p.d_blk, d_blk_chunks);
+                       d_flags, p.region, p.maxpass, const_cast<int32_t *>(d_blk_arg), d_blk_chunks, dry);
     return check_launch("k_plan_col16");
 }
 
@@ -958,10 +965,26 @@ static int build_col16(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
     SPMV_HIP_TRY(hipMemsetAsync(nblk.p, 0, sizeof(int32_t), s));
     if (want_blocks) SPMV_HIP_TRY(hipMalloc((void **)&p.d_blk, sizeof(int32_t) * (size_t)kBlkMax * (size_t)p.nchunks));
     int rc;
-    if (p.block == 256) rc = launch_plan_col16<256>(h, p, flags.p, nblk.p, s);
-    else if (p.block == 512) rc = launch_plan_col16<512>(h, p, flags.p, nblk.p, s);
-    else rc = launch_plan_col16<1024>(h, p, flags.p, nblk.p, s);
-    if (rc) return rc;
+    auto run = [&](const int32_t *blk_arg, int dry) {
+        if (p.block == 256) return launch_plan_col16<256>(h, p, flags.p, nblk.p, blk_arg, dry, s);
+        if (p.block == 512) return launch_plan_col16<512>(h, p, flags.p, nblk.p, blk_arg, dry, s);
+        return launch_plan_col16<1024>(h, p, flags.p, nblk.p, blk_arg, dry, s);
+    };
+    if (want_blocks) {
+        // counting run first: the block-list instantiation of the kernel costs every chunk a few percent (spills),
+        // so lists are used only where at least a quarter of the chunks want one (a stencil: all of them; a few wide
+        // chunks among power-law rows: not worth it)
+        if ((rc = run(p.d_blk, 1))) return rc;
+        int32_t cand = 0;
+        SPMV_HIP_TRY(hipMemcpyAsync(&cand, nblk.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SPMV_HIP_TRY(hipStreamSynchronize(s));
+        if (4 * (int64_t)cand < p.nchunks) {
+            (void)hipFree(p.d_blk);
+            p.d_blk = nullptr;
+        }
+        SPMV_HIP_TRY(hipMemsetAsync(nblk.p, 0, sizeof(int32_t), s));
+    }
+    if ((rc = run(p.d_blk, 0))) return rc;
     SPMV_HIP_TRY(hipMemcpyAsync(pos.p, flags.p, sizeof(int32_t) * (size_t)p.nchunks, hipMemcpyDeviceToDevice, s));
     if ((rc = exclusive_scan_i32(pos.p, p.nchunks, total.p, s))) return rc;
     hipLaunchKernelGGL(k_plan_lists, dim3((p.nchunks + 255) / 256), dim3(256), 0, s, p.nchunks, flags.p, pos.p, p.d_list16,
