@@ -188,3 +188,23 @@ def test_launcher_prototypes_match_the_reference_header():
     for name, types in ref.items():
         assert name in ours, name
         assert ours[name] == types, (name, ours[name], types)
+
+
+def test_stencil7_helper_matches_a_kron_laplacian(pkg):
+    """workloads.stencil7 (host-built 7-point stencil used by bench extras and GPU tests): pattern equals the
+    Kronecker-sum Laplacian, columns ascend inside every row, the scaling is per row."""
+    import scipy.sparse as sp
+    n = 5
+    N, rp, ci, va = pkg.workloads.stencil7(n)
+    assert N == n ** 3 and len(rp) == N + 1 and rp[-1] == len(ci) == len(va)
+    A = sp.csr_matrix((va, ci, rp), shape=(N, N))
+    T = sp.diags([1, 1, 1], [-1, 0, 1], shape=(n, n))
+    I = sp.identity(n)
+    L = (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T)).tocsr()
+    assert (abs(A.sign()) != (L != 0)).nnz == 0
+    for r in range(N):
+        cols = ci[rp[r]:rp[r + 1]]
+        assert np.all(np.diff(cols) > 0)
+        row = va[rp[r]:rp[r + 1]]
+        d = row[cols == r][0]
+        assert d > 0 and np.allclose(row[cols != r], -d / 6.0)
