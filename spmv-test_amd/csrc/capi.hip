@@ -294,7 +294,8 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
             return (int64_t)(h->plan_tiled.nchunks + 1) * 4 + (int64_t)h->plan_tiled.nchunks * 16 +
                    (h->plan_tiled.d_col16 ? (int64_t)h->plan_tiled.nchunks * 4 +
                                                 (int64_t)h->plan_tiled.n16 * 2 * h->plan_tiled.block * kNnzPerThread
-                                          : 0);
+                                          : 0) +
+                   (int64_t)h->plan_tiled.nblk_chunks * 256 * 4;   // block lists: up to 256 ids per chunk that has one
         case SPMV_PANEL:     // tile_ptr; packed/pvals REPLACE col_idx/vals byte for byte
             return (int64_t)h->plan_panel.nblocks * (h->plan_panel.npanels + 1) * 4 + ((int64_t)h->plan_panel.nblocks + 1) * 4;
         default: return 0;
