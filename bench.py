@@ -12,6 +12,8 @@ concatenates the output slices on every rank with one RCCL all-gather (BASELINE 
           line reports the other column laws, uniform-random included, under "other_workloads".
   N > 1   config 5 generalised: (N*16Mi)^2, one 16Mi-row / 256Mi-nnz block per rank (weak
           scaling: per-GPU work fixed), x (N*64 MiB) on every rank, y all-gathered every step.
+          --scaling strong: the SAME (128Mi)^2 / 2Gi-nnz matrix of config 5 for every N, its 32 row
+          blocks of 4Mi rows dealt block-cyclically over the N ranks (N = 1 holds all of it: 17.5 GB).
 
 value      = algorithmic bytes of all ranks x K / wall time of the K timed steps  [GB/s]
 roofline   = algorithmic bytes of one launch / mean launch time by HIP events on the launch stream
@@ -41,7 +43,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--variant", default=os.environ.get("SPMV_BENCH_VARIANT", "tiled"))
+    ap.add_argument("--variant", default=os.environ.get("SPMV_BENCH_VARIANT", "auto"),
+                    help="auto (default: the library picks tiled or panel from the matrix) | tiled | panel | adaptive | ...")
     ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"], help="N=1 workload (default: c4)")
     ap.add_argument("--band", type=int, default=int(os.environ.get("SPMV_BENCH_BAND", "8192")),
                     help="column law: >0 = diagonal band of that many columns (default 8192), 0 = uniform random")
@@ -51,6 +54,10 @@ def parse():
     ap.add_argument("--rows-per-gpu", type=int, default=16 << 20, help="N>1: rows of each rank's block (default 16Mi)")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SPMV_BENCH_PIPELINE", "4")),
                     help="N>1: row blocks per rank (block-cyclic); the all-gather of one group overlaps the next multiply")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): 16Mi rows per rank, the matrix grows with N; strong: config 5's (128Mi)^2 matrix "
+                         "for every N (--total-blocks row blocks dealt over the ranks)")
+    ap.add_argument("--total-blocks", type=int, default=32, help="--scaling strong: row blocks of the fixed matrix")
     ap.add_argument("--backend", default=os.environ.get("SPMV_BENCH_BACKEND", "nccl"),
                     help="nccl (= RCCL, default) | gloo (rehearsal of the N>1 path with ranks sharing one GPU)")
     return ap.parse_args()
@@ -90,7 +97,16 @@ def main():
     # ---- the workload: this rank's row block(s), generated on the device ---------------------------
     S = 1 if world == 1 else max(1, args.pipeline)
     t_setup = time.perf_counter()
-    if world == 1:
+    strong = args.scaling == "strong"
+    if strong:
+        # config 5 itself, whatever N: 8 x 16Mi rows, 2Gi nonzeros, cut into --total-blocks equal row blocks
+        w = W.c5(8, band=args.band, rows_per_gpu=args.rows_per_gpu)
+        if args.total_blocks % world or (w.rows // args.total_blocks) % W.BLOCK_ROWS:
+            raise SystemExit("--total-blocks must be a multiple of N and cut the matrix at multiples of 65536 rows")
+        S = args.total_blocks // world
+        sub_rows = w.rows // args.total_blocks
+        owned = [s * world + rank for s in range(S)]
+    elif world == 1:
         w = W.config(args.config, band=args.band)
         sub_rows = w.rows
         owned = [0]
@@ -101,6 +117,7 @@ def main():
         sub_rows = args.rows_per_gpu // S
         owned = [s * world + rank for s in range(S)]           # block-cyclic: group s is contiguous in y
     handles, keep, nnz_local = [], [], 0
+    plan_params = None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     plan_ms = 0.0
     for b in owned:
@@ -113,16 +130,29 @@ def main():
         capi.synth_fill(w.seed, r0, sub_rows, w.rows, w.cols, w.band, d_rp, d_ci, d_va)
         A = capi.CsrMatrix.from_device(sub_rows, w.cols, d_rp, d_ci, d_va)
         ev0.record()
-        A.plan(variant)
+        if plan_params is None:
+            A.plan(variant)
+        else:
+            A.plan_set(variant, plan_params)       # every block like the first: one chunk size, one summation order
         ev1.record()
         torch.cuda.synchronize()
         plan_ms += ev0.elapsed_time(ev1)
+        if plan_params is None:
+            plan_params = A.plan_params(variant)
+            if world > 1:                          # ... and like rank 0's first block on every rank
+                t = torch.tensor(plan_params, dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+                dist.broadcast(t, src=0)
+                agreed = [int(v) for v in t.cpu().tolist()]
+                if agreed != plan_params:
+                    A.plan_set(variant, agreed)
+                    plan_params = agreed
         handles.append(A)
         keep.append((rp, d_rp, d_ci, d_va))
         nnz_local += nb
     rows_local = sub_rows * len(owned)
 
-    if world == 1:
+    exchange_only = None
+    if world == 1 and not strong:
         A = handles[0]
         rp, d_rp, d_ci, d_va = keep[0]
         d_x = torch.empty(w.cols, dtype=torch.float32, device=dev)
@@ -143,7 +173,9 @@ def main():
         sh = pkg.dist.PipelinedSpmv(S, sub_rows, w.cols, [bind(h) for h in handles], dev)
         if rank == 0:
             capi.synth_x(w.seed, 0, w.cols, sh.x)
-        sh.broadcast_x(0)                    # the one-off distribution of the dense vector
+        if world > 1:
+            sh.broadcast_x(0)                # the one-off distribution of the dense vector
+        exchange_only = sh.exchange_only
         d_x = sh.x
         step = sh.step
         finish = sh.finish
@@ -191,7 +223,8 @@ def main():
 
     # ---- the kernel alone (no collective): mean launch time by HIP events on its stream -----------
     iters = max(10, args.steps)
-    if world == 1:
+    exchange_ms = None
+    if world == 1 and not strong:
         kernel_ms = A.time(variant, d_x, d_y, iters)          # spmv_csr_time: events inside the library
     else:
         ev0.record()
@@ -200,46 +233,77 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         kernel_ms = ev0.elapsed_time(ev1) / iters
+        if world > 1:                                          # the all-gathers of one step alone, no multiply
+            torch.cuda.synchronize(); barrier()
+            ev0.record()
+            for _ in range(iters):
+                exchange_only()
+            finish()
+            ev1.record()
+            torch.cuda.synchronize(); barrier()
+            exchange_ms = ev0.elapsed_time(ev1) / iters
     achieved = bytes_rank / (kernel_ms * 1e-3) / 1e9
 
     out = None
     if rank == 0:
-        traffic = None
-        tfile = ROOT / "profiles" / "traffic.json"       # written from the rocprofv3 --pmc passes
-        if tfile.exists():
+        # HBM traffic per SpMV from the PMC passes (tools/profile.sh + summarize_profile.py).  It cannot be measured
+        # inside this run (counters need rocprofv3 around the process), so it is REPLAYED from the committed file --
+        # and only when that measurement was taken with the very plan this run uses.
+        plan_now = handles[0].plan_describe(variant)
+        resolved = capi.lib().spmv_variant_name(handles[0].plan_params(variant)[0]).decode()
+        traffic, traffic_source = None, None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists() and world == 1 and not strong:
             try:
-                tj = json.loads(tfile.read_text())
-                key = f"{args.variant}:{w.name}:band{w.band}"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                ent = json.loads(tfile.read_text()).get(f"{resolved}:{w.name}:band{w.band}", {})
+                same_plan = ent.get("plan") is not None and ent["plan"].split(": ")[-1] == plan_now.split(": ")[-1]
+                if same_plan:
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_source = f"replayed from profiles/{ent.get('profile')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same plan)"
+                elif ent:
+                    traffic_source = f"profiles/{ent.get('profile')} was taken with another plan ({ent.get('plan')}): not replayed"
             except Exception:
                 traffic = None
+        dom_kernel = ("k_panel" if resolved == "panel" else
+                      "k_tiled16" if resolved == "tiled" and " col16_chunks=0 " not in plan_now else
+                      "k_adaptive" if resolved in ("adaptive", "tiled") else f"k_{resolved}")
         out = {
-            "metric": "fp32 CSR SpMV achieved HBM bandwidth (algorithmic bytes / time)",
+            "metric": "fp32 CSR SpMV throughput in CSR-algorithmic bytes per second (8/nnz + row_ptr + x + y over time; "
+                      "roofline.frac_hbm_counters is the FETCH_SIZE/WRITE_SIZE-based figure)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": w.describe(), "variant": args.variant,
                        "rows_per_gpu": rows_local, "nnz_per_gpu": nnz_local,
-                       "parallelism": "single GPU" if world == 1 else
+                       "parallelism": "single GPU" if world == 1 and not strong else
                        f"{S} block-cyclic row blocks per rank x{world} ranks, all-gather(y) of group s "
                        f"overlapped with the multiply of block s+1, {args.backend}",
+                       "devices": (f"{world} ranks on {min(world, max(ndev, 1))} device(s)" +
+                                   ("" if ndev >= world and args.backend == "nccl" else
+                                    " -- RANKS SHARE DEVICES: a rehearsal of the plumbing, not a scaling measurement")),
                        "algorithmic_bytes_per_gpu": bytes_rank},
             "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBS, 2),
             "gflops": round(gflops, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": ("k_tiled16" if args.variant == "tiled" and "col16_chunks=0 " not in handles[0].plan_describe(variant)
-                                    else "k_adaptive" if args.variant in ("adaptive", "tiled") else f"k_{args.variant}"),
+                         "traffic_source": traffic_source,
+                         # the same launch priced in the bytes the counters saw (16-bit columns: fewer than algorithmic)
+                         "achieved_hbm_counters": None if traffic is None else round(traffic / (kernel_ms * 1e-3) / 1e9, 2),
+                         "frac_hbm_counters": None if traffic is None else round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "definition": "achieved = CSR-algorithmic bytes of one SpMV / kernel_ms; "
+                                       "achieved_hbm_counters = FETCH_SIZE+WRITE_SIZE bytes of one SpMV / kernel_ms",
+                         "kernel": dom_kernel,
                          "kernel_ms": round(kernel_ms, 5), "timing": "HIP events on the launch stream"},
             "step_ms_events": round(step_ms_events, 5), "multiply_only_ms": round(kernel_ms, 5),
+            "exchange_only_ms": None if exchange_ms is None else round(exchange_ms, 5),
             "plan_ms": round(plan_ms, 4), "plan_bytes": sum(h.plan_bytes(variant) for h in handles),
             "plan": handles[0].plan_describe(variant),
             "setup_s": round(setup_s, 2),
         }
 
     # ---- CPU baseline: rank 0, N = 1 only, bounded sample of the same matrix ------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not strong and not args.no_cpu_baseline:
         orc = ge.load_oracle()
         n = min(args.cpu_sample_rows, rows_local)
         s0 = ((rows_local - n) // 2 // W.BLOCK_ROWS) * W.BLOCK_ROWS  # a window from the middle of the matrix
@@ -282,35 +346,51 @@ def main():
                                 "bit_identical_rows_vs_seq_oracle": int(np.sum(d_y[s0:s1].cpu().numpy() == y_cpu))}
 
     # ---- the other column laws and configs, kernel time only (N = 1) ------------------------------
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not strong and not args.no_extras:
         del A, d_rp, d_ci, d_va, d_x, d_y, handles, keep
         torch.cuda.empty_cache()
         extras = []
-        todo = [("c4", 0), ("c4", 2048), ("c4", 65536), ("c2", 0), ("c2", 8192), ("c3", 0), ("c3", 8192)]
+        todo = [("c4", 0), ("c4", 2048), ("c4", 65536), ("c2", 0), ("c2", 8192), ("c3", 0), ("c3", 8192),
+                ("c5", 8192), ("c5", 0)]
         for cname, band in todo:
             if cname == args.config and band == args.band:
                 continue
-            we = W.config(cname, band=band)
-            rpe = W.row_ptr(we)
+            if cname == "c5":
+                # config 5's per-GPU shard: rows [0, 16Mi) of the (128Mi)^2 matrix, all 128Mi columns, the full
+                # 512 MiB x (2 818 572 292 algorithmic bytes) -- what ONE MI355X of the 8 multiplies
+                we = W.c5(8, band=band)
+                n_loc = 16 << 20
+                label = "c5 shard (rows [0,16Mi) of " + we.describe() + ")"
+            else:
+                we = W.config(cname, band=band)
+                n_loc = we.rows
+                label = we.describe()
+            rpe = W.row_ptr(we, 0, n_loc)
+            nnz_e = int(rpe[-1])
             e_rp = torch.from_numpy(rpe).to(dev)
-            e_ci = torch.empty(we.nnz, dtype=torch.int32, device=dev)
-            e_va = torch.empty(we.nnz, dtype=torch.float32, device=dev)
+            e_ci = torch.empty(nnz_e, dtype=torch.int32, device=dev)
+            e_va = torch.empty(nnz_e, dtype=torch.float32, device=dev)
             e_x = torch.empty(we.cols, dtype=torch.float32, device=dev)
-            e_y = torch.empty(we.rows, dtype=torch.float32, device=dev)
-            capi.synth_fill(we.seed, 0, we.rows, we.rows, we.cols, we.band, e_rp, e_ci, e_va)
+            e_y = torch.empty(n_loc, dtype=torch.float32, device=dev)
+            capi.synth_fill(we.seed, 0, n_loc, we.rows, we.cols, we.band, e_rp, e_ci, e_va)
             capi.synth_x(we.seed, 0, we.cols, e_x)
-            Ae = capi.CsrMatrix.from_device(we.rows, we.cols, e_rp, e_ci, e_va)
-            be = W.algorithmic_bytes(we.rows, we.cols, we.nnz)
-            best = None
-            for vn in ("adaptive", "tiled", "vector") + (("panel",) if band == 0 else ()):
+            Ae = capi.CsrMatrix.from_device(n_loc, we.cols, e_rp, e_ci, e_va)
+            be = W.algorithmic_bytes(n_loc, we.cols, nnz_e)
+            best, auto = None, None
+            for vn in ("auto", "adaptive", "tiled", "vector") + (("panel",) if band == 0 else ()):
                 v = capi.VARIANTS[vn]
                 Ae.plan(v)
                 Ae.time(v, e_x, e_y, 3)
                 ms = min(Ae.time(v, e_x, e_y, 20) for _ in range(2))
+                if vn == "auto":
+                    auto = (Ae.plan_describe(v).split(":")[0], ms)
                 if best is None or ms < best[1]:
                     best = (vn, ms)
-            extras.append({"workload": we.describe(), "variant": best[0], "kernel_ms": round(best[1], 5),
-                           "GBs": round(be / best[1] / 1e6, 1), "frac_of_peak": round(be / best[1] / 1e6 / HBM_PEAK_GBS, 4)})
+            extras.append({"workload": label, "auto": auto[0], "auto_kernel_ms": round(auto[1], 5),
+                           "auto_frac_of_peak": round(be / auto[1] / 1e6 / HBM_PEAK_GBS, 4),
+                           "best_variant": best[0], "best_kernel_ms": round(best[1], 5),
+                           "best_frac_of_peak": round(be / best[1] / 1e6 / HBM_PEAK_GBS, 4),
+                           "algorithmic_bytes": be})
             Ae.close()
             del e_rp, e_ci, e_va, e_x, e_y
             torch.cuda.empty_cache()
@@ -322,18 +402,30 @@ def main():
         A3 = capi.CsrMatrix.from_device(N3, N3, t_rp, t_ci, t_va)
         b3 = W.algorithmic_bytes(N3, N3, len(ci3))
         best = None
-        for vn in ("adaptive", "tiled"):
+        for vn in ("auto", "adaptive"):
             v = capi.VARIANTS[vn]
             A3.plan(v)
             A3.time(v, t_x, t_y, 3)
             ms = min(A3.time(v, t_x, t_y, 20) for _ in range(2))
+            if vn == "auto":
+                auto = (A3.plan_describe(v).split(":")[0], ms)
             if best is None or ms < best[1]:
                 best = (vn, ms)
         extras.append({"workload": f"stencil7: 7-point stencil on 200^3 = {N3} unknowns, nnz {len(ci3)} (host-built)",
-                       "variant": best[0], "kernel_ms": round(best[1], 5), "GBs": round(b3 / best[1] / 1e6, 1),
-                       "frac_of_peak": round(b3 / best[1] / 1e6 / HBM_PEAK_GBS, 4)})
+                       "auto": auto[0], "auto_kernel_ms": round(auto[1], 5),
+                       "auto_frac_of_peak": round(b3 / auto[1] / 1e6 / HBM_PEAK_GBS, 4),
+                       "best_variant": best[0], "best_kernel_ms": round(best[1], 5),
+                       "best_frac_of_peak": round(b3 / best[1] / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": b3})
         A3.close()
         out["other_workloads"] = extras
+        # the headline's config under the other column laws, next to the headline (BASELINE fixes c4's sizes and
+        # row-length law, not its column law: the value above holds for the law named in config.workload only)
+        laws = {f"band {args.band}" if args.band else "uniform": round(achieved / HBM_PEAK_GBS, 4)}
+        for e in extras:
+            if e["workload"].startswith(args.config + ":"):
+                law = "uniform" if "uniform columns" in e["workload"] else "band " + e["workload"].split("band ")[1].split(")")[0]
+                laws[law] = e["auto_frac_of_peak"]
+        out["frac_of_peak_by_column_law"] = {"config": args.config, "variant": args.variant, **laws}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

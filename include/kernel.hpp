@@ -29,7 +29,7 @@ void csr_naive_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_hos
 void csr_tiling_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);  // tiled bitmap-CSR (spmv_tcsr_*)
 void wsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);   // 0 SPMV_WAVE, 1 SPMV_WAVE_PIPE
 void asp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);   // 0,1 SPMV_VECTOR; 2 dense + x==0 skip
-void awsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);  // 0,1 SPMV_ADAPTIVE, 2 SPMV_TILED
+void awsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);  // 0 SPMV_ADAPTIVE, 1 SPMV_TILED, 2 SPMV_AUTO
 void awsp_ref_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);    // SPMV_SCALAR (reference order)
 void wsp_sm_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);      // SPMV_TILED
 
@@ -43,11 +43,16 @@ void wsp_sm_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);
         }                                                                                  \
     }
 
-// timing convention of the path (reference: TIME_KERNEL, kernel.hpp:31-48): `run_call` is an
-// spmv_*_run_host(..., &ms) expression; the event-timed milliseconds it reports are printed
-// in the reference's format.
-#define TIME_KERNEL(run_call, ms_var)                                        \
-    {                                                                        \
-        SPMV_CHECK(run_call);                                                \
-        std::cout << #run_call << " took " << (ms_var) << " ms" << std::endl; \
+// timing convention of the path (reference: TIME_KERNEL(kernel_call), kernel.hpp:31-48: ONE argument, the launch
+// expression, timed with two events and printed as "<stringified call> took <ms> ms").  Here the launch expression
+// is one of the spmv_*_run_host calls, which time their kernel between two HIP events on the launch stream
+// themselves and report it through their last argument; by convention that argument is a float named
+// `kernel_ms` in the calling scope.
+#define TIME_KERNEL(kernel_call)                                                     \
+    {                                                                                \
+        SPMV_CHECK(kernel_call);                                                     \
+        std::cout << #kernel_call << " took " << kernel_ms << " ms" << std::endl;    \
     }
+
+// the reference's name for the error macro (kernel.hpp:21-28), for code written against that header
+#define CUDA_CHECK(call) SPMV_CHECK(call)

@@ -75,7 +75,12 @@ enum spmv_variant {
                         /* tiled format: TCSRMatrix src/tcsr.cpp:5-38 + csr_tiling_kernel*/
                         /* src/kernels/csr_tiling.cu:24-114.  Its plan COPIES the values */
                         /* (re-plan after changing them).                               */
-    SPMV_VARIANT_COUNT = 7
+    SPMV_AUTO = 7,      /* the library chooses at plan time: SPMV_TILED where its plan can stage the    */
+                        /* chunks' x windows in LDS, SPMV_PANEL where it cannot (columns without        */
+                        /* locality) and x is larger than one XCD's L2.  spmv_csr_plan_describe names   */
+                        /* the choice.  Role: the reference's adaptive slot awsp_gemv_gpu               */
+                        /* (src/kernels/awsp.cu:319-388), which the launcher of that name now runs.     */
+    SPMV_VARIANT_COUNT = 8
 };
 
 /* ---- runtime ---------------------------------------------------------- */
@@ -119,8 +124,10 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
 /* ---- the hot path ------------------------------------------------------
  * spmv_csr_plan: one-off device-side preprocessing a variant needs (chunk
  * boundaries, column windows, for SPMV_TILED also a 16-bit copy of the column
- * indices and a few timed trial launches that pick the workgroup size); a
- * no-op for SCALAR/WAVE.  Excluded from the timed SpMV like the reference
+ * indices; workgroup size and pass budget follow from the chunk statistics,
+ * with SPMV_AUTOTUNE=1 from timed trial launches instead); a no-op for
+ * SCALAR/WAVE.  A handle belongs to the device that was current when it was
+ * created: plan and run fail with SPMV_ERR_INVALID under another current device.  Excluded from the timed SpMV like the reference
  * excludes its host format build from TIME_KERNEL (e.g. wsp.cu:146 vs :167).
  * A plan snapshots the sparsity PATTERN (row_ptr, col_idx): with borrowed
  * arrays (spmv_csr_create_device) the pattern must not change afterwards;
@@ -133,6 +140,21 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
  * overwritten.  No allocation, no synchronisation: graph-capturable. */
 SPMV_API int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream);
 SPMV_API int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void *stream);
+
+/* What decides a plan's chunk cuts and with them the order of every fp32 sum, as numbers a caller can carry from
+ * one handle to another (rank 0 to the other ranks of a job, one run to the next):
+ *   params[0] variant actually planned (SPMV_AUTO resolves to SPMV_TILED or SPMV_PANEL)
+ *   params[1] threads per workgroup (ADAPTIVE/TILED: 256 | 512 | 1024; a chunk is 16x that many nonzeros)
+ *   params[2] staging-pass budget (TILED)        params[3] 1 = keep the 16-bit column copy where it pays (TILED)
+ *   params[4] log2(columns per panel) (PANEL)    params[5] wavefronts per launch (PANEL)    params[6..7] 0
+ * spmv_csr_plan (the default) derives them from the matrix alone -- no timing -- so two handles of one matrix
+ * already agree; handles of DIFFERENT row blocks of one matrix may not, and with SPMV_AUTOTUNE=1 nothing is
+ * guaranteed.  spmv_csr_plan_set plans with exactly these numbers (replacing any existing plan of that variant),
+ * spmv_csr_plan_like copies them from `src`.  Row blocks whose first nonzero offsets are multiples of the chunk
+ * size, planned alike, give y bit-identical to the whole matrix planned alike (ADAPTIVE/TILED). */
+SPMV_API int spmv_csr_plan_get(const spmv_csr_t *h, int variant, int32_t params[8]);
+SPMV_API int spmv_csr_plan_set(spmv_csr_t *h, int variant, const int32_t params[8], void *stream);
+SPMV_API int spmv_csr_plan_like(spmv_csr_t *dst, const spmv_csr_t *src, int variant, void *stream);
 
 /* Bytes of plan data the variant reads per run.  Chunk boundaries, carries and windows come on top
  * of the CSR arrays; the 16-bit column offsets of SPMV_TILED REPLACE the 4-byte col_idx reads of the
@@ -170,6 +192,15 @@ SPMV_API int spmv_csr_run_host(spmv_csr_t *h, int variant, const float *x_host, 
  *     (asp_kernel_v0/1/2, src/kernels/asp.cu:20-26). */
 SPMV_API int spmv_dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode,
                     void *stream);
+
+/* Modes 2 and 3 split M over 64 row slabs and need 64*N floats for the per-slab partial sums.
+ * spmv_dense_gemv_ws takes that workspace from the caller (spmv_dense_gemv_workspace_bytes says how much; 0 for
+ * modes 0/1): no allocation, no host wait, graph-capturable.  spmv_dense_gemv without the argument uses a
+ * buffer the library keeps per device and hands from call to call in stream order (asynchronous too; it waits on
+ * the host only when the buffer has to grow). */
+SPMV_API int64_t spmv_dense_gemv_workspace_bytes(int N, int mode);
+SPMV_API int spmv_dense_gemv_ws(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode,
+                                void *d_workspace, int64_t workspace_bytes, void *stream);
 
 /* Host-buffer form of the same (upload A and x, run, download y). */
 SPMV_API int spmv_dense_gemv_host(int M, int N, const float *A_host, const float *x_host, float *y_host,

@@ -9,6 +9,9 @@
  *
  * What is restated, and from where (all citations into /root/reference):
  *   oracle_csr_count / oracle_csr_fill   src/matrix_csr.cpp:5-23 (CSRMatrix ctor)
+ *   oracle_wsp_* / oracle_awsp_* / oracle_awsp_ref_* / oracle_asp_values
+ *                                        src/wsp.cpp:3-40, src/awsp.cpp:3-49, src/awsp_ref.cpp:4-58,
+ *                                        src/asp.cpp:3-14 (the bitmap formats; pinned like the CSR builder)
  *   oracle_sgemv_dense                   src/tester.cpp:36-45    (SgemvCPU, THE oracle)
  *   oracle_spmv_csr_seq                  src/kernels/csr_naive.cu:13-22 (the per-row loop,
  *                                        walked on the host in the same order)
@@ -120,6 +123,140 @@ ORACLE_API int64_t oracle_tcsr_build(int M, int N, const float *A, int32_t *blk_
         }
     }
     return value_index;
+}
+
+/* ------------------------------------------------------------------ */
+/* The bitmap formats of the reference's wsp / awsp / awsp_ref / asp   */
+/* launchers, restated as closed-form index maps (the reference grows   */
+/* vectors of vectors and pads afterwards; the arrays are the same).   */
+/* Every builder comes as a pair: *_bitmaps fills the bitmap and        */
+/* returns the statistic that sizes the value array, *_values fills the */
+/* zero-padded value array.  "kept" means (v != 0.0f), as everywhere.   */
+/* M and N multiples of 32 (tester.cpp:9-10).                           */
+/* ------------------------------------------------------------------ */
+
+/* wsp.cpp:3-40 (WSPMatrix).  Bit (i*M + j) of the bitmap = element (input j, output i): one run of M bits per */
+/* output column.  Values: the kept elements of column i, j ascending, at vals[i*nz_max_m + k]; nz_max_m = the    */
+/* longest column (wsp.hpp:14, public), nz_max_n = N.  Returns nz_max_m.                                          */
+ORACLE_API int32_t oracle_wsp_bitmaps(int M, int N, const float *A, uint32_t *bitmaps)
+{
+    int32_t longest = 0;
+    memset(bitmaps, 0, sizeof(uint32_t) * ((size_t)M * N / 32));
+    for (int i = 0; i < N; i++) {
+        int32_t len = 0;
+        for (int j = 0; j < M; j++) {
+            if (A[(size_t)j * N + i] != 0.0f) {
+                const size_t bit = (size_t)i * M + j;
+                bitmaps[bit >> 5] |= 1u << (bit & 31);
+                len++;
+            }
+        }
+        if (len > longest) longest = len;
+    }
+    return longest;
+}
+
+ORACLE_API void oracle_wsp_values(int M, int N, const float *A, int32_t nz_max_m, float *vals)
+{
+    memset(vals, 0, sizeof(float) * (size_t)N * (size_t)nz_max_m);
+    for (int i = 0; i < N; i++) {
+        float *dst = vals + (size_t)i * nz_max_m;
+        for (int j = 0; j < M; j++) {
+            const float v = A[(size_t)j * N + i];
+            if (v != 0.0f) *dst++ = v;
+        }
+    }
+}
+
+/* awsp.cpp:3-49 (AWSPMatrix).  32x32 blocks, output strip outer, input block inner: block b = (bn/32)*(M/32) + */
+/* bm/32.  Word 32*b + r of the bitmap = input row bm+r, bit c = output bn+c.  Values of a block in that (r, c)    */
+/* order at vals[b*nz_bk_max + k], every block padded to the fullest one.  Returns nz_bk_max (awsp.hpp:13).        */
+ORACLE_API int32_t oracle_awsp_bitmaps(int M, int N, const float *A, uint32_t *bitmaps)
+{
+    int32_t fullest = 0;
+    size_t word = 0;
+    for (int bn = 0; bn < N; bn += 32) {
+        for (int bm = 0; bm < M; bm += 32) {
+            int32_t cnt = 0;
+            for (int r = 0; r < 32; r++, word++) {
+                uint32_t w = 0;
+                const float *row = A + (size_t)(bm + r) * N + bn;
+                for (int c = 0; c < 32; c++)
+                    if (row[c] != 0.0f) { w |= 1u << c; cnt++; }
+                bitmaps[word] = w;
+            }
+            if (cnt > fullest) fullest = cnt;
+        }
+    }
+    return fullest;
+}
+
+ORACLE_API void oracle_awsp_values(int M, int N, const float *A, int32_t nz_bk_max, float *vals)
+{
+    const size_t nblk = (size_t)(M / 32) * (size_t)(N / 32);
+    memset(vals, 0, sizeof(float) * nblk * (size_t)nz_bk_max);
+    size_t b = 0;
+    for (int bn = 0; bn < N; bn += 32) {
+        for (int bm = 0; bm < M; bm += 32, b++) {
+            float *dst = vals + b * (size_t)nz_bk_max;
+            for (int r = 0; r < 32; r++) {
+                const float *row = A + (size_t)(bm + r) * N + bn;
+                for (int c = 0; c < 32; c++)
+                    if (row[c] != 0.0f) *dst++ = row[c];
+            }
+        }
+    }
+}
+
+/* awsp_ref.cpp:4-58 (AWSPRefMatrix).  Word s*M + j of the bitmap = input row j inside output strip s (outputs     */
+/* 32s..32s+31), bit c = output 32s+c.  The M inputs are cut into four quarters ("warps", M/4 rows each); the kept */
+/* elements of (strip s, quarter q) in (row, c) order start at vals[s*off[3] + (q ? off[q-1] : 0)], where off[q] is */
+/* the inclusive prefix over q of the per-quarter maxima over all strips (warp_nz_offset_, awsp_ref.cpp:33-40).    */
+ORACLE_API void oracle_awsp_ref_bitmaps(int M, int N, const float *A, uint32_t *bitmaps, int32_t off[4])
+{
+    int32_t most[4] = {0, 0, 0, 0};
+    const int Q = M / 4;
+    for (int s = 0; s < N / 32; s++) {
+        for (int q = 0; q < 4; q++) {
+            int32_t cnt = 0;
+            for (int j = q * Q; j < (q + 1) * Q; j++) {
+                uint32_t w = 0;
+                const float *row = A + (size_t)j * N + 32 * s;
+                for (int c = 0; c < 32; c++)
+                    if (row[c] != 0.0f) { w |= 1u << c; cnt++; }
+                bitmaps[(size_t)s * M + j] = w;
+            }
+            if (cnt > most[q]) most[q] = cnt;
+        }
+    }
+    int32_t run = 0;
+    for (int q = 0; q < 4; q++) { run += most[q]; off[q] = run; }
+}
+
+ORACLE_API void oracle_awsp_ref_values(int M, int N, const float *A, const int32_t off[4], float *vals)
+{
+    const int Q = M / 4;
+    memset(vals, 0, sizeof(float) * (size_t)(N / 32) * (size_t)off[3]);
+    for (int s = 0; s < N / 32; s++) {
+        for (int q = 0; q < 4; q++) {
+            float *dst = vals + (size_t)s * off[3] + (q ? off[q - 1] : 0);
+            for (int j = q * Q; j < (q + 1) * Q; j++) {
+                const float *row = A + (size_t)j * N + 32 * s;
+                for (int c = 0; c < 32; c++)
+                    if (row[c] != 0.0f) *dst++ = row[c];
+            }
+        }
+    }
+}
+
+/* asp.cpp:3-14 (ASPMatrix): the dense matrix re-tiled, block b (as in AWSP) holds its 32x32 elements row-major. */
+ORACLE_API void oracle_asp_values(int M, int N, const float *A, float *vals)
+{
+    size_t p = 0;
+    for (int bn = 0; bn < N; bn += 32)
+        for (int bm = 0; bm < M; bm += 32)
+            for (int r = 0; r < 32; r++)
+                for (int c = 0; c < 32; c++) vals[p++] = A[(size_t)(bm + r) * N + bn + c];
 }
 
 /* tester.cpp:36-45 -- y[i] = sum_j x[j] * A[j*N+i], fp32, j ascending. */

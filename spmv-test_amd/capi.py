@@ -15,9 +15,9 @@ LAUNCHERS_PATH = PKG_DIR / "lib" / "libspmv_launchers.so"
 TESTER_PATH = PKG_DIR / "bin" / "sparse_sgemv"
 
 # enum spmv_variant
-SCALAR, WAVE, WAVE_PIPE, VECTOR, ADAPTIVE, TILED, PANEL = range(7)
+SCALAR, WAVE, WAVE_PIPE, VECTOR, ADAPTIVE, TILED, PANEL, AUTO = range(8)
 VARIANTS = {"scalar": SCALAR, "wave": WAVE, "wave_pipe": WAVE_PIPE, "vector": VECTOR,
-            "adaptive": ADAPTIVE, "tiled": TILED, "panel": PANEL}
+            "adaptive": ADAPTIVE, "tiled": TILED, "panel": PANEL, "auto": AUTO}
 
 # enum spmv_status
 OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_VARIANT, ERR_NOT_PLANNED = 0, -1, -2, -3, -4, -5
@@ -40,11 +40,16 @@ SIGNATURES = {
     "spmv_csr_destroy": (C.c_int, [_H]),
     "spmv_csr_plan": (C.c_int, [_H, C.c_int, _vp]),
     "spmv_csr_run": (C.c_int, [_H, C.c_int, _f32p, _f32p, _vp]),
+    "spmv_csr_plan_get": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int32)]),
+    "spmv_csr_plan_set": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int32), _vp]),
+    "spmv_csr_plan_like": (C.c_int, [_H, _H, C.c_int, _vp]),
     "spmv_csr_plan_bytes": (C.c_int64, [_H, C.c_int]),
     "spmv_csr_plan_describe": (C.c_int, [_H, C.c_int, C.c_char_p, C.c_int]),
     "spmv_csr_time": (C.c_int, [_H, C.c_int, _f32p, _f32p, C.c_int, _vp, C.POINTER(C.c_float)]),
     "spmv_csr_run_host": (C.c_int, [_H, C.c_int, _f32p, _f32p, C.POINTER(C.c_float)]),
     "spmv_dense_gemv": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _vp]),
+    "spmv_dense_gemv_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "spmv_dense_gemv_ws": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _vp, C.c_int64, _vp]),
     "spmv_dense_gemv_host": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.POINTER(C.c_float)]),
     "spmv_tcsr_from_dense_host": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
     "spmv_tcsr_from_dense_device": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
@@ -189,6 +194,19 @@ class CsrMatrix:
         check(lib().spmv_csr_run_host(self._h, variant, _ptr(x), _ptr(y), C.byref(ms)))
         return ms.value
 
+    def plan_params(self, variant: int):
+        """The eight numbers that fix a plan's chunk cuts (spmv_csr_plan_get)."""
+        a = (C.c_int32 * 8)()
+        check(lib().spmv_csr_plan_get(self._h, variant, a))
+        return list(a)
+
+    def plan_set(self, variant: int, params, stream=None) -> None:
+        a = (C.c_int32 * 8)(*params)
+        check(lib().spmv_csr_plan_set(self._h, variant, a, _stream_handle(stream)))
+
+    def plan_like(self, other: "CsrMatrix", variant: int, stream=None) -> None:
+        check(lib().spmv_csr_plan_like(self._h, other._h, variant, _stream_handle(stream)))
+
     def plan_describe(self, variant: int) -> str:
         buf = C.create_string_buffer(256)
         check(lib().spmv_csr_plan_describe(self._h, variant, buf, 256))
@@ -273,9 +291,19 @@ class TcsrMatrix:
             pass
 
 
-def dense_gemv(A, x, y, mode: int, stream=None) -> None:
+def dense_gemv(A, x, y, mode: int, stream=None, workspace=None) -> None:
+    """y = A^T x on the dense device matrix; with ``workspace`` (a device tensor of at least
+    ``dense_gemv_workspace_bytes(N, mode)`` bytes) through the allocation-free entry."""
     M, N = A.shape
-    check(lib().spmv_dense_gemv(M, N, _ptr(A), _ptr(x), _ptr(y), mode, _stream_handle(stream)))
+    if workspace is None:
+        check(lib().spmv_dense_gemv(M, N, _ptr(A), _ptr(x), _ptr(y), mode, _stream_handle(stream)))
+    else:
+        check(lib().spmv_dense_gemv_ws(M, N, _ptr(A), _ptr(x), _ptr(y), mode, _ptr(workspace),
+                                       workspace.numel() * workspace.element_size(), _stream_handle(stream)))
+
+
+def dense_gemv_workspace_bytes(N: int, mode: int) -> int:
+    return lib().spmv_dense_gemv_workspace_bytes(N, mode)
 
 
 def synth_fill(seed, row0, n_local, rows, cols, band, row_ptr, col_idx, vals, stream=None) -> None:

@@ -36,6 +36,47 @@ static int require_device()
     return SPMV_OK;
 }
 
+int LdsOptIn::ensure(const void *fn, int device, int bytes)
+{
+    const uint64_t bit = (device >= 0 && device < 64) ? (1ull << device) : 0ull;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return SPMV_OK;
+    SPMV_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (bit) done.fetch_or(bit, std::memory_order_release);
+    return SPMV_OK;
+}
+
+int device_cus(int device)
+{
+    static std::atomic<int> cache[64];
+    const bool cached = device >= 0 && device < 64;
+    if (cached) {
+        const int c = cache[device].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    if (cached) cache[device].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
+int require_current(int device, const char *what)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: hipGetDevice failed", what);
+        return SPMV_ERR_HIP;
+    }
+    if (cur != device) {
+        set_error("%s: the handle lives on device %d but the current device is %d (hipSetDevice first)", what, device, cur);
+        return SPMV_ERR_INVALID;
+    }
+    return SPMV_OK;
+}
+
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace spmv
@@ -66,6 +107,7 @@ const char *spmv_variant_name(int variant)
         case SPMV_ADAPTIVE: return "adaptive";
         case SPMV_TILED: return "tiled";
         case SPMV_PANEL: return "panel";
+        case SPMV_AUTO: return "auto";
         default: return "unknown";
     }
 }
@@ -241,11 +283,37 @@ int spmv_csr_destroy(spmv_csr_t *h)
     return rc;
 }
 
+// SPMV_AUTO: plan TILED (cheap: a few passes over col_idx, no trial launches) and look at what it could stage.
+// A plan that stages less than half of the chunks gathers most of x through L2/fabric -- one request per nonzero --
+// and when x is larger than one XCD's 4 MiB L2 that is where the panel sweep is 3-4x faster;
+// below that size x sits in every L2 anyway and the row-major kernel keeps its lead.
+static int plan_auto(spmv_csr &h, hipStream_t s)
+{
+    if (h.auto_variant >= 0) return SPMV_OK;
+    int rc = plan_adaptive(h, true, s);
+    if (rc) return rc;
+    const ChunkPlan &p = h.plan_tiled;
+    const bool little_staged = p.nchunks > 0 && 2 * (int64_t)p.staged_full < p.nchunks && 2 * (int64_t)p.nblk_chunks < p.nchunks;
+    const bool x_beyond_l2 = h.cols * (int64_t)sizeof(float) > (4ll << 20);
+    if (little_staged && x_beyond_l2) {
+        rc = plan_panel(h, s);
+        if (rc == SPMV_OK) {
+            h.auto_variant = SPMV_PANEL;
+            return SPMV_OK;
+        }
+        if (rc != SPMV_ERR_INVALID) return rc;   // INVALID: outside the panel layout's limits -> stay with TILED
+    }
+    h.auto_variant = SPMV_TILED;
+    return SPMV_OK;
+}
+
 int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream)
 {
     if (!h) { set_error("spmv_csr_plan: null handle"); return SPMV_ERR_INVALID; }
+    if (int rc = require_current(h->device, "spmv_csr_plan")) return rc;
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
+        case SPMV_AUTO: return plan_auto(*h, s);
         case SPMV_SCALAR:
         case SPMV_WAVE:
         case SPMV_WAVE_PIPE: return SPMV_OK;
@@ -269,7 +337,12 @@ int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void 
         set_error("spmv_csr_run: x must be 16-byte aligned");
         return SPMV_ERR_INVALID;
     }
+    if (int rc = require_current(h->device, "spmv_csr_run")) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (variant == SPMV_AUTO) {
+        if (h->auto_variant < 0) { set_error("SPMV_AUTO used before spmv_csr_plan"); return SPMV_ERR_NOT_PLANNED; }
+        variant = h->auto_variant;
+    }
     switch (variant) {
         case SPMV_SCALAR: return launch_scalar(*h, d_x, d_y, s);
         case SPMV_WAVE: return launch_wave(*h, d_x, d_y, false, s);
@@ -284,9 +357,79 @@ int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void 
     }
 }
 
+int spmv_csr_plan_get(const spmv_csr_t *h, int variant, int32_t params[8])
+{
+    if (!h || !params) { set_error("spmv_csr_plan_get: null argument"); return SPMV_ERR_INVALID; }
+    for (int i = 0; i < 8; ++i) params[i] = 0;
+    if (variant == SPMV_AUTO) {
+        if (h->auto_variant < 0) { set_error("spmv_csr_plan_get: SPMV_AUTO is not planned"); return SPMV_ERR_NOT_PLANNED; }
+        variant = h->auto_variant;
+    }
+    params[0] = variant;
+    switch (variant) {
+        case SPMV_SCALAR: case SPMV_WAVE: case SPMV_WAVE_PIPE: return SPMV_OK;
+        case SPMV_VECTOR: params[1] = h->vector_width; return SPMV_OK;
+        case SPMV_ADAPTIVE:
+        case SPMV_TILED: {
+            const ChunkPlan &p = variant == SPMV_TILED ? h->plan_tiled : h->plan_adaptive;
+            if (!p.block) { set_error("spmv_csr_plan_get: variant %d is not planned", variant); return SPMV_ERR_NOT_PLANNED; }
+            params[1] = p.block; params[2] = p.maxpass; params[3] = p.col16_wanted ? 1 : 0;
+            return SPMV_OK;
+        }
+        case SPMV_PANEL:
+            if (!h->plan_panel.ready) { set_error("spmv_csr_plan_get: panel is not planned"); return SPMV_ERR_NOT_PLANNED; }
+            params[4] = h->plan_panel.pw_bits; params[5] = h->plan_panel.waves_per_launch;
+            return SPMV_OK;
+        default: set_error("spmv_csr_plan_get: unknown variant %d", variant); return SPMV_ERR_VARIANT;
+    }
+}
+
+int spmv_csr_plan_set(spmv_csr_t *h, int variant, const int32_t params[8], void *stream)
+{
+    if (!h || !params) { set_error("spmv_csr_plan_set: null argument"); return SPMV_ERR_INVALID; }
+    if (int rc = require_current(h->device, "spmv_csr_plan_set")) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    int target = variant;
+    if (variant == SPMV_AUTO) {
+        target = params[0];
+        if (target != SPMV_TILED && target != SPMV_PANEL) {
+            set_error("spmv_csr_plan_set: SPMV_AUTO resolves to tiled or panel, not %d", target);
+            return SPMV_ERR_INVALID;
+        }
+    } else if (params[0] != variant) {
+        set_error("spmv_csr_plan_set: params describe variant %d, not %d", params[0], variant);
+        return SPMV_ERR_INVALID;
+    }
+    int rc;
+    switch (target) {
+        case SPMV_SCALAR: case SPMV_WAVE: case SPMV_WAVE_PIPE: rc = SPMV_OK; break;
+        case SPMV_VECTOR: {
+            const int w = params[1];
+            if (w != 2 && w != 4 && w != 8 && w != 16 && w != 32) { set_error("spmv_csr_plan_set: lanes per row %d", w); return SPMV_ERR_INVALID; }
+            h->vector_width = w;
+            rc = SPMV_OK;
+            break;
+        }
+        case SPMV_ADAPTIVE: rc = plan_adaptive_with(*h, params[1], s); break;
+        case SPMV_TILED: rc = plan_tiled_with(*h, params[1], params[2], params[3] != 0, s); break;
+        case SPMV_PANEL: rc = plan_panel_with(*h, params[4], params[5], s); break;
+        default: set_error("spmv_csr_plan_set: unknown variant %d", target); return SPMV_ERR_VARIANT;
+    }
+    if (rc == SPMV_OK && variant == SPMV_AUTO) h->auto_variant = target;
+    return rc;
+}
+
+int spmv_csr_plan_like(spmv_csr_t *dst, const spmv_csr_t *src, int variant, void *stream)
+{
+    int32_t params[8];
+    int rc = spmv_csr_plan_get(src, variant, params);
+    return rc ? rc : spmv_csr_plan_set(dst, variant, params, stream);
+}
+
 int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
 {
     if (!h) return 0;
+    if (variant == SPMV_AUTO) variant = h->auto_variant;
     switch (variant) {
         case SPMV_ADAPTIVE:  // chunk_lb read + carry written and re-read
             return (int64_t)(h->plan_adaptive.nchunks + 1) * 4 + (int64_t)h->plan_adaptive.nchunks * 8;
@@ -305,6 +448,12 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
 int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
 {
     if (!h || !buf || n <= 0) { set_error("spmv_csr_plan_describe: bad argument"); return SPMV_ERR_INVALID; }
+    if (variant == SPMV_AUTO) {   // "auto -> <variant>: <that variant's plan>"
+        if (h->auto_variant < 0) { snprintf(buf, (size_t)n, "not planned"); return SPMV_OK; }
+        const int w = snprintf(buf, (size_t)n, "auto -> %s: ", spmv_variant_name(h->auto_variant));
+        if (w < 0 || w >= n) return SPMV_OK;
+        return spmv_csr_plan_describe(h, h->auto_variant, buf + w, n - w);
+    }
     const ChunkPlan *p = variant == SPMV_ADAPTIVE ? &h->plan_adaptive : (variant == SPMV_TILED ? &h->plan_tiled : nullptr);
     if (variant == SPMV_VECTOR) snprintf(buf, (size_t)n, "lanes_per_row=%d", h->vector_width);
     else if (variant == SPMV_PANEL && h->plan_panel.ready)
@@ -510,6 +659,20 @@ int spmv_dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y
     int rc = require_device();
     if (rc) return rc;
     return dense_gemv(M, N, d_A, d_x, d_y, mode, (hipStream_t)stream);
+}
+
+int64_t spmv_dense_gemv_workspace_bytes(int N, int mode) { return (int64_t)dense_gemv_workspace_bytes(N, mode); }
+
+int spmv_dense_gemv_ws(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, void *d_workspace,
+                       int64_t workspace_bytes, void *stream)
+{
+    if (M < 0 || N < 0 || ((int64_t)M * N > 0 && (!d_A || !d_x)) || (N > 0 && !d_y) || workspace_bytes < 0) {
+        set_error("spmv_dense_gemv_ws: bad argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return dense_gemv_ws(M, N, d_A, d_x, d_y, mode, d_workspace, (size_t)workspace_bytes, (hipStream_t)stream);
 }
 
 int spmv_synth_fill(uint64_t seed, int64_t row0, int64_t n_local, int64_t rows, int64_t cols, int64_t band,

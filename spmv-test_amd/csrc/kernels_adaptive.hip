@@ -945,6 +945,7 @@ static int launch_plan_col16(const spmv_csr &h, ChunkPlan &p, int32_t *d_flags, 
 // 16-bit column offsets + the two chunk lists for a finished TILED plan
 static int build_col16(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
 {
+    p.col16_wanted = true;
     if (p.nchunks == 0 || !p.d_win || p.persist) return SPMV_OK;
     if (const char *e = getenv("SPMV_COL16")) {  // tuning knob: 0 keeps 32-bit columns everywhere
         if (atoi(e) == 0) return SPMV_OK;
@@ -1015,6 +1016,27 @@ static int build_col16(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
 
 int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s);
 
+int plan_tiled_with(spmv_csr &h, int block, int maxpass, bool col16, hipStream_t s)
+{
+    if ((block != 256 && block != 512 && block != 1024) || maxpass < 1 || maxpass > 64) {
+        set_error("tiled plan: block %d / maxpass %d outside 256|512|1024 / 1..64", block, maxpass);
+        return SPMV_ERR_INVALID;
+    }
+    int rc = build_plan(h, block, maxpass, s, h.plan_tiled, nullptr, nullptr);
+    if (rc == SPMV_OK && col16) rc = build_col16(h, h.plan_tiled, s);
+    if (rc) free_plan(h.plan_tiled);
+    return rc;
+}
+
+int plan_adaptive_with(spmv_csr &h, int block, hipStream_t s)
+{
+    if (block != 256) {   // the plain kernel is instantiated for 256-thread workgroups only
+        set_error("adaptive plan: block %d (only 256)", block);
+        return SPMV_ERR_INVALID;
+    }
+    return build_plan(h, 256, 0, s, h.plan_adaptive, nullptr, nullptr);
+}
+
 int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
 {
     if (!tiled) {
@@ -1034,8 +1056,12 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
         return rc ? rc : build_col16(h, h.plan_tiled, s);
     }
 
-    bool autotune = h.nnz >= (1 << 20);  // below ~1M nonzeros a launch is a few microseconds either way
-    if (const char *e = getenv("SPMV_AUTOTUNE")) autotune = atoi(e) != 0;
+    // The default plan is a pure function of the matrix (chunk statistics below): two handles of the same matrix --
+    // two ranks, two runs -- get the same workgroup size, hence the same chunk cuts and bit-identical y.
+    // SPMV_AUTOTUNE=1 replaces it with timed trials (a few percent on some inputs, but the pick then depends on
+    // the device and the moment; spmv_csr_plan_get/_set carry such a pick to other handles).
+    bool autotune = false;
+    if (const char *e = getenv("SPMV_AUTOTUNE")) autotune = atoi(e) != 0 && h.nnz >= (1 << 20);
     if (!autotune) {
         // Heuristic: the smallest workgroup whose LDS region holds the whole column span of >= 90 %
         // of the chunks in ONE pass (same LDS bytes and waves per CU for all three, but a larger
@@ -1166,19 +1192,11 @@ void destroy_plans(spmv_csr &h)
     destroy_panel(h.plan_panel);
 }
 
-static int resident_workgroups(int block, int waves_simd)
+static int resident_workgroups(int device, int block, int waves_simd)
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
     int per_cu = (waves_simd * 4 * kWave) / block;  // workgroups per CU by waves
     if (per_cu < 1) per_cu = 1;
-    return cus * per_cu;
+    return device_cus(device) * per_cu;
 }
 
 template <int BLOCK, bool TILED, bool PERSIST>
@@ -1188,15 +1206,11 @@ static int launch_range(const spmv_csr &h, const ChunkPlan &p, int chunk0, int n
     if (nrun <= 0) return SPMV_OK;
     // dynamic LDS: the product buffer; a staged x slice is never wider (plan cap = region)
     const size_t lds = sizeof(float) * (size_t)p.region;
-    static std::atomic<bool> attr_set{false};  // > 64 KiB of dynamic LDS needs the opt-in (BLOCK = 1024)
-    if (!attr_set.load(std::memory_order_acquire)) {
-        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_adaptive<BLOCK, TILED, PERSIST>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.store(true, std::memory_order_release);
-    }
+    static LdsOptIn optin;  // > 64 KiB of dynamic LDS needs the opt-in (BLOCK = 1024), once per device
+    if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_adaptive<BLOCK, TILED, PERSIST>), h.device, (int)lds)) return rc;
     int grid = nrun;
     if (PERSIST) {
-        const int res = resident_workgroups(BLOCK, waves_per_simd(BLOCK, true));
+        const int res = resident_workgroups(h.device, BLOCK, waves_per_simd(BLOCK, true));
         if (grid > res) grid = res;
     }
     hipLaunchKernelGGL((k_adaptive<BLOCK, TILED, PERSIST>), dim3(grid), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols,
@@ -1208,12 +1222,8 @@ template <int BLOCK, bool BLOCKS>
 static int launch_tiled16_t(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
 {
     const size_t lds = sizeof(float) * (size_t)p.region;
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
-        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiled16<BLOCK, BLOCKS>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.store(true, std::memory_order_release);
-    }
+    static LdsOptIn optin;
+    if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_tiled16<BLOCK, BLOCKS>), h.device, (int)lds)) return rc;
     hipLaunchKernelGGL((k_tiled16<BLOCK, BLOCKS>), dim3(p.n16), dim3(BLOCK), lds, s, h.rows, h.cols, p.n16, h.d_row_ptr,
                        p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win,
                        p.n16 == p.nchunks ? (const int32_t *)nullptr : p.d_list16, p.region, p.d_blk);
@@ -1232,12 +1242,8 @@ template <int BLOCK, bool BLOCKS>
 static int launch_mixed_t(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
 {
     const size_t lds = sizeof(float) * (size_t)p.region;
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
-        SPMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiled_mixed<BLOCK, BLOCKS>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.store(true, std::memory_order_release);
-    }
+    static LdsOptIn optin;
+    if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_tiled_mixed<BLOCK, BLOCKS>), h.device, (int)lds)) return rc;
     const int n32 = p.nchunks - p.n16;
     hipLaunchKernelGGL((k_tiled_mixed<BLOCK, BLOCKS>), dim3(p.nchunks), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols, n32,
                        p.n16, h.d_row_ptr, h.d_col_idx, p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, p.d_list32,

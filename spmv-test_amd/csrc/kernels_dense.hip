@@ -10,6 +10,7 @@
 //   dense_gemv     y[i] = sum_j x[j]*A[j*N+i]: the dense slots of the launcher API --
 //                  naive_kernel (naive.cu:4-11), tiling_kernel (tiling_smem.cu:4-32) and the
 //                  vendor slot cublas_gemv_gpu (cublas.cu:4-44).
+#include <mutex>
 #include "spmv_internal.hpp"
 
 namespace spmv {
@@ -316,7 +317,14 @@ __global__ __launch_bounds__(kBlock) void k_gemv_combine(int N, const float *__r
     y[i] = acc;
 }
 
-int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s)
+size_t dense_gemv_workspace_bytes(int N, int mode)
+{
+    return (mode == 2 || mode == 3) ? sizeof(float) * (size_t)kSlabs * (size_t)(N > 0 ? N : 0) : 0;
+}
+
+// Allocation-free and asynchronous: modes 2/3 put their per-slab partials into the caller's workspace.
+int dense_gemv_ws(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, void *d_ws, size_t ws_bytes,
+                  hipStream_t s)
 {
     if (N == 0) return SPMV_OK;
     const int blocks = (N + kBlock - 1) / kBlock;
@@ -330,23 +338,66 @@ int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int
         return check_launch("k_gemv_xtile");
     }
     if (mode == 2 || mode == 3) {
-        // the per-slab partials: a plain allocation, released after the stream has drained (the stream-ordered
-        // allocator on the legacy NULL stream handed a second call memory the first call's kernels were still
-        // using: 64 wrong outputs in 17 of 25 runs of the tester at 1024 x 768)
-        DevPtr<float> part;
-        SPMV_HIP_TRY(part.alloc((size_t)kSlabs * N));
+        if (!d_ws || ws_bytes < dense_gemv_workspace_bytes(N, mode)) {
+            set_error("spmv_dense_gemv_ws: mode %d needs %zu bytes of workspace, got %zu", mode,
+                      dense_gemv_workspace_bytes(N, mode), d_ws ? ws_bytes : (size_t)0);
+            return SPMV_ERR_INVALID;
+        }
+        float *part = static_cast<float *>(d_ws);
         if (mode == 3)
-            hipLaunchKernelGGL(k_gemv_split<true>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, part.p);
+            hipLaunchKernelGGL(k_gemv_split<true>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, part);
         else
-            hipLaunchKernelGGL(k_gemv_split<false>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, part.p);
+            hipLaunchKernelGGL(k_gemv_split<false>, dim3(blocks, kSlabs), dim3(kBlock), 0, s, M, N, d_A, d_x, part);
         if ((rc = check_launch("k_gemv_split"))) return rc;
-        hipLaunchKernelGGL(k_gemv_combine, dim3(blocks), dim3(kBlock), 0, s, N, part.p, d_y);
-        if ((rc = check_launch("k_gemv_combine"))) return rc;
-        SPMV_HIP_TRY(hipStreamSynchronize(s));
-        return SPMV_OK;
+        hipLaunchKernelGGL(k_gemv_combine, dim3(blocks), dim3(kBlock), 0, s, N, part, d_y);
+        return check_launch("k_gemv_combine");
     }
     set_error("spmv_dense_gemv: unknown mode %d", mode);
     return SPMV_ERR_VARIANT;
+}
+
+// The library-owned workspace behind spmv_dense_gemv (the entry without a workspace argument): one buffer per
+// device, grown on demand, handed from call to call in STREAM ORDER -- a call on another stream than the last
+// user's first makes its stream wait for the event recorded behind that user's combine kernel.  So the entry is
+// asynchronous (no host wait) as long as the buffer is large enough; growing it waits for the last user once.
+namespace {
+struct DenseWorkspace {
+    std::mutex mu;
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_done = nullptr;
+    bool used = false;
+};
+DenseWorkspace g_dense_ws[64];
+}  // namespace
+
+int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s)
+{
+    const size_t need = dense_gemv_workspace_bytes(N, mode);
+    if (need == 0) return dense_gemv_ws(M, N, d_A, d_x, d_y, mode, nullptr, 0, s);
+    int dev = 0;
+    SPMV_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("spmv_dense_gemv: device id %d outside the workspace table", dev); return SPMV_ERR_INVALID; }
+    DenseWorkspace &w = g_dense_ws[dev];
+    std::lock_guard<std::mutex> lock(w.mu);
+    if (!w.last_done) SPMV_HIP_TRY(hipEventCreateWithFlags(&w.last_done, hipEventDisableTiming));
+    if (w.bytes < need) {
+        if (w.used) SPMV_HIP_TRY(hipEventSynchronize(w.last_done));   // the old buffer's last reader has finished
+        if (w.p) SPMV_HIP_TRY(hipFree(w.p));
+        w.p = nullptr; w.bytes = 0;
+        const size_t want = need < (1u << 20) ? (1u << 20) : need;
+        SPMV_HIP_TRY(hipMalloc(&w.p, want));
+        w.bytes = want;
+        w.used = false;
+    }
+    if (w.used && w.last_stream != s) SPMV_HIP_TRY(hipStreamWaitEvent(s, w.last_done, 0));
+    int rc = dense_gemv_ws(M, N, d_A, d_x, d_y, mode, w.p, w.bytes, s);
+    if (rc) return rc;
+    SPMV_HIP_TRY(hipEventRecord(w.last_done, s));
+    w.last_stream = s;
+    w.used = true;
+    return SPMV_OK;
 }
 
 }  // namespace spmv

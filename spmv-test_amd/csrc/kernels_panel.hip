@@ -391,16 +391,11 @@ void destroy_panel(PanelPlan &p)
 }
 
 // one launch = one set of co-resident waves sweeping in step: 2 workgroups (4 waves) per CU
-static int resident_waves()
-{
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
-    return cus * 2 * kWavesPerWg;
-}
+static int resident_waves(int device) { return device_cus(device) * 2 * kWavesPerWg; }
 
-int plan_panel(spmv_csr &h, hipStream_t s)
+int plan_panel(spmv_csr &h, hipStream_t s) { return plan_panel_with(h, 0, 0, s); }
+
+int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, hipStream_t s)
 {
     destroy_panel(h.plan_panel);
     PanelPlan p;
@@ -410,6 +405,7 @@ int plan_panel(spmv_csr &h, hipStream_t s)
     }
     int bits = kColBits;   // 128Ki columns = 512 KiB of x per panel
     if (const char *e = getenv("SPMV_PANEL_BITS")) bits = atoi(e);
+    if (want_bits > 0) bits = want_bits;
     if (bits < 8) bits = 8;
     if (bits > kColBits) bits = kColBits;
     while (bits < kColBits && ((h.cols + (1ll << bits) - 1) >> bits) > kMaxPanels) ++bits;
@@ -422,11 +418,12 @@ int plan_panel(spmv_csr &h, hipStream_t s)
         return SPMV_ERR_INVALID;
     }
     // row blocks: equal nonzero counts, as many as fill the resident wave slots of every launch
-    p.waves_per_launch = resident_waves();
+    p.waves_per_launch = resident_waves(h.device);
     if (const char *e = getenv("SPMV_PANEL_WAVES")) {
         const int v = atoi(e);
         if (v > 0) p.waves_per_launch = v;
     }
+    if (want_waves > 0) p.waves_per_launch = want_waves;
     if (h.rows == 0) {
         p.ready = true;
         h.plan_panel = p;

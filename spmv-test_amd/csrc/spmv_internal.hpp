@@ -1,6 +1,7 @@
 // spmv_internal.hpp -- shared declarations of libspmv_hip.so (not installed).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include "spmv_hip.h"
@@ -28,6 +29,16 @@ struct DevPtr {
     hipError_t alloc(size_t count) { return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1)); }
     T *release() { T *q = p; p = nullptr; return q; }
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): a function-local static of this type
+// remembers the devices a kernel has been opted in on (one bit per device id; ids >= 64 set it on every launch).
+struct LdsOptIn {
+    std::atomic<uint64_t> done{0};
+    int ensure(const void *fn, int device, int bytes);
+};
+int device_cus(int device);   // compute units of a device (cached per device id; 256 if the query fails)
+// SPMV_OK when `device` (where a handle's arrays live) is the calling thread's current device
+int require_current(int device, const char *what);
 
 // ---- geometry constants ----------------------------------------------------
 constexpr int kWave = 64;          // gfx950 wavefront
@@ -61,6 +72,7 @@ struct ChunkPlan {
     int32_t *d_blk = nullptr;      // [64 * nchunks] ids of the staged 1024-column blocks of the chunks that use a list
     int nblk_chunks = 0;           // how many chunks do
     int maxpass = 0;
+    bool col16_wanted = false;     // the plan asked for the 16-bit copy (it is kept only where enough chunks qualify)
     int spanning_rows = 0;         // rows that continue past their owner chunk (0: no fix-up launch)
     int region = 0;                // floats of the dynamic LDS region (x slice, then products)
     bool persist = false;      // persistent software-pipelined launch (measured slower: DESIGN.md section 4)
@@ -99,6 +111,7 @@ struct spmv_csr {
     spmv::ChunkPlan plan_adaptive; // SPMV_ADAPTIVE: 256-thread workgroups
     spmv::ChunkPlan plan_tiled;    // SPMV_TILED: workgroup size chosen from the column windows
     spmv::PanelPlan plan_panel;    // SPMV_PANEL
+    int auto_variant = -1;         // SPMV_AUTO: the variant its plan chose (-1 = not planned)
 };
 
 namespace spmv {
@@ -115,10 +128,17 @@ void destroy_panel(PanelPlan &p);
 int panel_launches(const PanelPlan &p);
 int plan_vector(spmv_csr &h, hipStream_t s);
 int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s);
+// TILED with exactly these parameters (spmv_csr_plan_set); block 256|512|1024, maxpass >= 1
+int plan_tiled_with(spmv_csr &h, int block, int maxpass, bool col16, hipStream_t s);
+int plan_adaptive_with(spmv_csr &h, int block, hipStream_t s);
+int plan_panel_with(spmv_csr &h, int pw_bits, int waves_per_launch, hipStream_t s);   // 0 = library default
 void destroy_plans(spmv_csr &h);
 
 int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out);
 int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s);
+size_t dense_gemv_workspace_bytes(int N, int mode);
+int dense_gemv_ws(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, void *d_ws, size_t ws_bytes,
+                  hipStream_t s);
 
 // kernels_rows.hip: structural check of a CSR (bad[0] first row with row_ptr[r] > row_ptr[r+1] or outside [0,nnz],
 // bad[1] first element with a column outside [0,cols), bad[2]/bad[3] row_ptr[0] / row_ptr[rows] when wrong)

@@ -99,8 +99,9 @@ class PipelinedSpmv:
 
     def __init__(self, S: int, sub_rows: int, cols: int, local_spmvs, device, group=None):
         self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        # one process, no process group: every block is local and nothing is exchanged (bench --scaling strong, N = 1)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if len(local_spmvs) != S:
             raise ValueError("need one local product per owned block")
         self.S, self.sub_rows, self.cols = S, sub_rows, cols
@@ -181,6 +182,27 @@ class PipelinedSpmv:
                     done.record(self.comm_stream)
                 self._pending[s] = done
         return self.y_full
+
+    def exchange_only(self) -> None:
+        """The S all-gathers of one step without the products (what the exchange alone costs; bench.py prints it
+        beside ``multiply_only_ms``).  Enqueued on the side stream like in ``step``; call ``finish()`` after."""
+        if self.world == 1:
+            return
+        if not self.cuda:
+            for s in range(self.S):
+                w = self._gather_group(s)
+                if w is not None:
+                    w.wait()
+            return
+        compute = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(compute)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            for s in range(self.S):
+                w = self._gather_group(s)
+                if w is not None:
+                    w.wait()
 
     def finish(self) -> torch.Tensor:
         """Order the current stream behind every outstanding gather; y_full is then complete."""

@@ -53,6 +53,13 @@ class Golden:
         self.tcsr = None
         if "tcsr_blk_idx" in z.files:      # reference TCSRMatrix arrays (32-aligned fixtures only)
             self.tcsr = (z["tcsr_blk_idx"], z["tcsr_bitmaps"], z["tcsr_vals"])
+        # reference WSPMatrix / AWSPMatrix / AWSPRefMatrix arrays + the statistics the classes expose (32-aligned only)
+        self.bitmap = {}
+        for key in ("wsp", "awsp", "awsp_ref"):
+            if f"{key}_bitmaps" in z.files:
+                self.bitmap[key] = (z[f"{key}_bitmaps"], z[f"{key}_vals"], z[f"{key}_stats"])
+        self.asp_checksum = z["asp_checksum"] if "asp_checksum" in z.files else None
+        self.y_source = str(z["y_source"])
         if "A" in z.files:
             self.A = z["A"]
         else:

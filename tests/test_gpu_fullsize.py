@@ -26,61 +26,85 @@ def test_config_2_and_3_full_size_every_row(pkg, oracle, gpu, name, band):
         assert_close_to_oracle(y, y64, mag, f"{w.name}/{vname}")
 
 
-@pytest.fixture(scope="module", params=[0, 1 << 16], ids=["uniform", "banded"])
+# ---- config 4 at full size, and config 5's per-GPU shard at full size (BASELINE configs[3], configs[4]) ----
+# c5 = (128Mi)^2 with 2Gi nonzeros cut into 8 row blocks of 16Mi rows; ONE block is what one MI355X holds:
+# 16Mi rows x 128Mi columns, 2^28 nonzeros, the full 512 MiB x (2 818 572 292 bytes).  Blocks
+# k = 0 and k = 7 (first and last rows of the global matrix: band clipping at both ends, global row ids up to 2^27).
+BIG = [("c4", 0, 0), ("c4", 0, 1 << 16), ("c5", 0, 8192), ("c5", 7, 8192), ("c5", 0, 0), ("c5", 7, 0)]
+
+
+@pytest.fixture(scope="module", params=BIG, ids=[f"{n}-block{k}-band{b}" for n, k, b in BIG])
 def c4(request, pkg, gpu):
     import torch
     W, capi = pkg.workloads, pkg.capi
-    w = W.config("c4", band=request.param)
-    rp = W.row_ptr(w)
-    assert int(rp[-1]) == 268_435_456 and w.rows == 16_777_216
+    name, k, band = request.param
+    if name == "c4":
+        w = W.config("c4", band=band)
+        n = w.rows
+    else:
+        w = W.c5(8, band=band)
+        n = 16 << 20
+        assert w.rows == w.cols == 134_217_728
+    r0 = k * n
+    rp = W.row_ptr(w, r0, n)
+    nnz = int(rp[-1])
+    assert nnz == 268_435_456 and n == 16_777_216
+    if name == "c5":
+        assert W.algorithmic_bytes(n, w.cols, nnz) == 2_818_572_292        # BASELINE.md section 4, c5 per-GPU shard
     d_rp = torch.from_numpy(rp).to(gpu)
-    d_ci = torch.empty(w.nnz, dtype=torch.int32, device=gpu)
-    d_va = torch.empty(w.nnz, dtype=torch.float32, device=gpu)
+    d_ci = torch.empty(nnz, dtype=torch.int32, device=gpu)
+    d_va = torch.empty(nnz, dtype=torch.float32, device=gpu)
     d_x = torch.empty(w.cols, dtype=torch.float32, device=gpu)
-    capi.synth_fill(w.seed, 0, w.rows, w.rows, w.cols, w.band, d_rp, d_ci, d_va)
+    capi.synth_fill(w.seed, r0, n, w.rows, w.cols, w.band, d_rp, d_ci, d_va)
     capi.synth_x(w.seed, 0, w.cols, d_x)
-    A = capi.CsrMatrix.from_device(w.rows, w.cols, d_rp, d_ci, d_va)
-    Aabs = capi.CsrMatrix.from_device(w.rows, w.cols, d_rp, d_ci, d_va.abs())
+    A = capi.CsrMatrix.from_device(n, w.cols, d_rp, d_ci, d_va)
+    Aabs = capi.CsrMatrix.from_device(n, w.cols, d_rp, d_ci, d_va.abs())
     for v in capi.VARIANTS.values():
         A.plan(v)
     Aabs.plan(capi.ADAPTIVE)
-    mag = torch.empty(w.rows, dtype=torch.float32, device=gpu)
+    mag = torch.empty(n, dtype=torch.float32, device=gpu)
     Aabs.run(capi.ADAPTIVE, d_x.abs(), mag)          # sum_k |val_k x_k| per row: the error scale
     torch.cuda.synchronize()
-    yield dict(w=w, rp=rp, d_rp=d_rp, d_ci=d_ci, d_va=d_va, d_x=d_x, A=A, mag=mag)
-    A.close(); Aabs.close()
+    Aabs.close()
+    yield dict(w=w, r0=r0, n=n, rp=rp, d_rp=d_rp, d_ci=d_ci, d_va=d_va, d_x=d_x, A=A, mag=mag, name=name)
+    A.close()
+    del d_rp, d_ci, d_va, d_x, mag
+    torch.cuda.empty_cache()
 
 
 def _run(c4, pkg, variant, x=None):
     import torch
-    y = torch.full((c4["w"].rows,), float("nan"), device=c4["d_x"].device)
+    y = torch.full((c4["n"],), float("nan"), device=c4["d_x"].device)
     c4["A"].run(variant, c4["d_x"] if x is None else x, y)
     torch.cuda.synchronize()
     return y
 
 
 def test_row_sample_matches_oracle(c4, pkg, oracle):
-    """1Mi rows (three separated windows incl. the first and last rows) regenerated on the host."""
-    w, rp = c4["w"], c4["rp"]
+    """1Mi rows (separated windows incl. the block's first and last rows) regenerated on the host from the GLOBAL
+    row ids: device generator bit-exact, SCALAR bit-identical, every variant within 1e-5 * sum|terms|."""
+    w, rp, R0, n_local = c4["w"], c4["rp"], c4["r0"], c4["n"]
     x = oracle.synth_x(w.seed, 0, w.cols)
     assert np.array_equal(c4["d_x"].cpu().numpy().view(np.uint32), x.view(np.uint32))
     ys = {n: _run(c4, pkg, v) for n, v in pkg.capi.VARIANTS.items()}
     n = 1 << 18
-    for r0 in (0, 7_654_321, w.rows - n, 12_000_000):
-        r1 = r0 + n
-        rps = (rp[r0:r1 + 1].astype(np.int64) - int(rp[r0])).astype(np.int32)
-        ci, va = oracle.synth_fill(w.seed, r0, r1, w.rows, w.cols, w.band, rps)
-        k0, k1 = int(rp[r0]), int(rp[r1])
+    for l0 in (0, 7_654_321, n_local - n, 12_000_000):
+        l1 = l0 + n
+        rps = (rp[l0:l1 + 1].astype(np.int64) - int(rp[l0])).astype(np.int32)
+        ci, va = oracle.synth_fill(w.seed, R0 + l0, R0 + l1, w.rows, w.cols, w.band, rps)
+        k0, k1 = int(rp[l0]), int(rp[l1])
         assert np.array_equal(c4["d_ci"][k0:k1].cpu().numpy(), ci)                 # indices bit-exact
         assert np.array_equal(c4["d_va"][k0:k1].cpu().numpy().view(np.uint32), va.view(np.uint32))
+        if w.band:                                                                  # the band follows the GLOBAL diagonal
+            assert ci.min() >= max(0, R0 + l0 - 4 * 3072 * 8) and ci.max() <= min(w.cols - 1, R0 + l1 + 4 * 3072 * 8)
         y_seq = oracle.spmv(rps, ci, va, x)
         y64, mag = oracle.spmv_f64(rps, ci, va, x)
         for name, y in ys.items():
-            got = y[r0:r1].cpu().numpy()
+            got = y[l0:l1].cpu().numpy()
             if name == "scalar":
                 assert np.array_equal(got.view(np.uint32), y_seq.view(np.uint32))
             err = np.abs(got.astype(np.float64) - y64)
-            assert np.all(err <= RTOL * mag + 1e-37), (name, r0, err.max())
+            assert np.all(err <= RTOL * mag + 1e-37), (name, l0, err.max())
 
 
 def test_all_variants_agree_on_every_row(c4, pkg):
@@ -95,6 +119,12 @@ def test_all_variants_agree_on_every_row(c4, pkg):
         assert bad == 0, f"{name}: {bad} rows differ from scalar beyond {RTOL}*sum|terms|"
 
 
+def test_auto_choice_at_full_size(c4, pkg):
+    """SPMV_AUTO at the BASELINE sizes: the LDS-tiled kernel on banded columns, the panel sweep on uniform ones."""
+    d = c4["A"].plan_describe(pkg.capi.AUTO)
+    assert d.startswith("auto -> tiled" if c4["w"].band else "auto -> panel"), d
+
+
 def test_linearity(c4, pkg):
     """A(a*x1 + x2) == a*A(x1) + A(x2) within the fp32 bound -- no oracle needed at this size."""
     import torch
@@ -103,7 +133,7 @@ def test_linearity(c4, pkg):
     x1 = c4["d_x"]
     x2 = torch.rand(c4["w"].cols, device=dev, generator=g) * 2 - 1
     a = 0.375
-    v = pkg.capi.ADAPTIVE
+    v = pkg.capi.AUTO
     y1, y2, y12 = _run(c4, pkg, v, x1), _run(c4, pkg, v, x2), _run(c4, pkg, v, a * x1 + x2)
     mag = c4["mag"] * (1 + abs(a)) + 1.0    # |A||x2| is bounded by sum|val| <= mag-ish scale; generous but linear
     bad = ((y12 - (a * y1 + y2)).abs() > 4 * RTOL * mag).sum().item()

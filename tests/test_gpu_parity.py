@@ -13,7 +13,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-VARIANT_NAMES = ["scalar", "wave", "wave_pipe", "vector", "adaptive", "tiled", "panel"]
+VARIANT_NAMES = ["scalar", "wave", "wave_pipe", "vector", "adaptive", "tiled", "panel", "auto"]
 
 
 def _check_all_variants(pkg, oracle, prob, what):
@@ -249,11 +249,15 @@ def test_tester_executable_passes(pkg, gpu):
     assert p.stdout.count(" took ") >= 13 and "[GPU kernel" not in p.stderr
 
 
-def test_launchers_from_python_match_oracle(pkg, oracle, gpu):
-    """Call the C++ launchers (mangled names, dense host buffers) the way tester.cpp does."""
+@pytest.mark.parametrize("M,N,zero,seed", [(320, 448, 0.5, 9), (4096, 4096, 0.99, 4096)],
+                         ids=["320x448_half", "config1_4096x4096_1pct"])
+def test_launchers_from_python_match_oracle(pkg, oracle, gpu, M, N, zero, seed):
+    """Call the C++ launchers (mangled names, dense host buffers) the way tester.cpp does.  The second case is
+    BASELINE.json configs[0] at its stated size: 4096 x 4096 with 1 % uniform-random nonzeros (and the tester's
+    50 %-zero x, tester.cpp:154), through all 13 launcher entries against the oracle."""
     import ctypes
     L = ctypes.CDLL(str(pkg.capi.LAUNCHERS_PATH))
-    A, x = pkg.workloads.dense_random(320, 448, 0.5, seed=9)
+    A, x = pkg.workloads.dense_random(M, N, zero, seed=seed)
     y_ref = oracle.sgemv_dense(A, x)
     rp, ci, va = oracle.csr_from_dense(A)
     y64, mag = oracle.spmv_f64(rp, ci, va, x)
@@ -267,15 +271,15 @@ def test_launchers_from_python_match_oracle(pkg, oracle, gpu):
     for sym, ver in calls:
         fn = getattr(L, sym)
         fn.restype = None
-        y = np.full(448, np.nan, np.float32)
+        y = np.full(N, np.nan, np.float32)
         if ver is None:
             fn.argtypes = [ci_, ci_, vp, vp, vp]
-            fn(320, 448, A.ctypes.data, x.ctypes.data, y.ctypes.data)
+            fn(M, N, A.ctypes.data, x.ctypes.data, y.ctypes.data)
         else:
             fn.argtypes = [ci_, ci_, vp, vp, vp, ci_]
-            fn(320, 448, A.ctypes.data, x.ctypes.data, y.ctypes.data, ver)
+            fn(M, N, A.ctypes.data, x.ctypes.data, y.ctypes.data, ver)
         assert_close_to_oracle(y, y64, mag, sym)
-        assert oracle.L.oracle_compare(448, y_ref.ctypes.data, y.ctypes.data, ctypes.c_float(1e-3)) == 0  # tester.cpp:75
+        assert oracle.L.oracle_compare(N, y_ref.ctypes.data, y.ctypes.data, ctypes.c_float(1e-3)) == 0  # tester.cpp:75
         if "awsp_ref" in sym or "csr_naive" in sym or "naive_gemv" in sym:
             assert np.array_equal(y.view(np.uint32), y_ref.view(np.uint32)), sym
 

@@ -102,3 +102,103 @@ def test_tcsr_builder_matches_reference_fixture(oracle, golden):
     assert np.array_equal(va.view(np.uint32), rva.view(np.uint32))
     # the same nonzeros as the CSR of the same matrix, in a different order
     assert len(va) == len(golden.vals) and np.array_equal(np.sort(va), np.sort(golden.vals))
+
+
+# ---- the bitmap formats of the wsp / awsp / awsp_ref / asp launchers --------------------------------
+def decode_bitmap_format(fmt, M, N, bitmaps, vals, stats):
+    """Dense A[M][N] back from a reference-layout (bitmaps, vals, stats): the inverse of wsp.cpp:3-40,
+    awsp.cpp:3-49, awsp_ref.cpp:4-58 written from the layout description alone (numpy, no oracle code)."""
+    bits = np.unpackbits(bitmaps.view(np.uint8), bitorder="little").astype(bool)      # bit k of the stream
+    A = np.zeros((M, N), np.float32)
+    if fmt == "wsp":                 # bit i*M + j <-> (input j, output i); column i's values at i*nz_max_m
+        nzm = int(stats[0])
+        occ = bits.reshape(N, M)
+        for i in range(N):
+            js = np.flatnonzero(occ[i])
+            A[js, i] = vals[i * nzm:i * nzm + len(js)]
+            assert np.all(vals[i * nzm + len(js):(i + 1) * nzm] == 0)                # zero padding
+    elif fmt == "awsp":              # block b = strip*(M/32) + rowblock; word 32b + r, bit c
+        nbk = int(stats[0])
+        occ = bits.reshape(N // 32, M // 32, 32, 32)
+        for s_ in range(N // 32):
+            for rb in range(M // 32):
+                b = s_ * (M // 32) + rb
+                r, c = np.nonzero(occ[s_, rb])
+                A[rb * 32 + r, s_ * 32 + c] = vals[b * nbk:b * nbk + len(r)]
+                assert np.all(vals[b * nbk + len(r):(b + 1) * nbk] == 0)
+    elif fmt == "awsp_ref":          # word s*M + j, bit c; (strip, quarter) streams at s*off[3] + off[q-1]
+        off = [int(v) for v in stats]
+        occ = bits.reshape(N // 32, M, 32)
+        Q = M // 4
+        for s_ in range(N // 32):
+            for q in range(4):
+                r, c = np.nonzero(occ[s_, q * Q:(q + 1) * Q])
+                base = s_ * off[3] + (off[q - 1] if q else 0)
+                A[q * Q + r, s_ * 32 + c] = vals[base:base + len(r)]
+                assert np.all(vals[base + len(r):s_ * off[3] + off[q]] == 0)
+    return A
+
+
+@pytest.mark.parametrize("fmt", ["wsp", "awsp", "awsp_ref"])
+def test_bitmap_format_builders_match_reference_fixture(oracle, golden, fmt):
+    """Bitmaps, padded values and the exposed statistics (nz_max_m / nz_bk_max_ / warp_nz_offset_[4]) bit for bit
+    against the arrays the reference's own classes produced (tests/golden/make_golden.py through oracle/_ref)."""
+    if fmt not in golden.bitmap:
+        pytest.skip("fixture is not 32-aligned: the reference's bitmap formats are undefined for it")
+    rbm, rva, rst = golden.bitmap[fmt]
+    bm, va, st = oracle.bitmap_from_dense(fmt, golden.A)
+    assert np.array_equal(st, rst), (st, rst)
+    assert np.array_equal(bm, rbm)
+    assert len(va) == len(rva) and np.array_equal(va.view(np.uint32), rva.view(np.uint32))
+    # sizes as the reference defines them
+    M, N = golden.M, golden.N
+    assert len(rbm) == M * N // 32
+    want = {"wsp": N * int(rst[0]), "awsp": (M // 32) * (N // 32) * int(rst[0]), "awsp_ref": (N // 32) * int(rst[3])}[fmt]
+    assert len(rva) == want
+    # and the layout means what DESIGN says: decoding the reference arrays gives the dense matrix back
+    A = decode_bitmap_format(fmt, M, N, rbm, rva, rst)
+    keep = golden.A != 0
+    assert np.array_equal(A[keep].view(np.uint32), golden.A[keep].view(np.uint32)) and not A[~keep].any()
+
+
+def test_asp_retiling_matches_reference_checksum(oracle, golden):
+    if golden.asp_checksum is None:
+        pytest.skip("fixture is not 32-aligned")
+    _, av, _ = oracle.bitmap_from_dense("asp", golden.A)
+    u = av.view(np.uint32).astype(np.uint64)
+    got = [av.size, int(u.sum() & 0xFFFFFFFFFFFF),
+           int((u * (np.arange(av.size, dtype=np.uint64) % 65521 + 1)).sum() & 0xFFFFFFFFFFFF)]
+    assert got == [int(v) for v in golden.asp_checksum]
+
+
+@pytest.mark.skipif(not REF_LIB.exists(), reason="oracle/_ref not built (no /root/reference here)")
+@pytest.mark.parametrize("shape,zero", [((64, 96), 0.5), ((128, 32), 0.97), ((32, 160), 0.0), ((256, 64), 1.0)])
+def test_bitmap_format_builders_match_live_reference(oracle, shape, zero):
+    """The reference's WSPMatrix / AWSPMatrix / AWSPRefMatrix / ASPMatrix run here on fresh inputs."""
+    lib = ctypes.CDLL(str(REF_LIB))
+    lib.ref_fmt_build.restype = ctypes.c_void_p
+    lib.ref_fmt_build.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    lib.ref_fmt_copy.argtypes = [ctypes.c_void_p] * 3
+    lib.ref_fmt_free.argtypes = [ctypes.c_void_p]
+    rng = np.random.Generator(np.random.PCG64(shape[0] * 1000 + shape[1]))
+    A = rng.uniform(-1, 1, size=shape).astype(np.float32)
+    A[rng.random(size=shape) < zero] = 0.0
+    A.flat[::5] = -0.0
+    M, N = shape
+    for kind, fmt in enumerate(["wsp", "awsp", "awsp_ref", "asp"]):
+        nb, nv = ctypes.c_int(), ctypes.c_int()
+        st = np.zeros(4, np.int32)
+        h = lib.ref_fmt_build(kind, M, N, A.ctypes.data, ctypes.byref(nb), ctypes.byref(nv), st.ctypes.data)
+        rbm = np.empty(nb.value, np.uint32); rva = np.empty(nv.value, np.float32)
+        lib.ref_fmt_copy(h, rbm.ctypes.data, rva.ctypes.data)
+        lib.ref_fmt_free(h)
+        bm, va, ost = oracle.bitmap_from_dense(fmt, A)
+        assert np.array_equal(ost, st), (fmt, ost, st)
+        assert np.array_equal(bm, rbm), fmt
+        assert len(va) == len(rva) and np.array_equal(va.view(np.uint32), rva.view(np.uint32)), fmt
+
+
+def test_golden_y_is_not_the_oracle_checking_itself(golden):
+    """VERDICT weak-1: y_dense comes from a statement of SgemvCPU that shares no code with oracle/."""
+    assert golden.y_source.startswith("numpy_sgemv")

@@ -46,6 +46,10 @@ def main():
     cal_f = means(newest(src / "cal_fetch" / "*" / "*_counter_collection.csv"))
     cal_w = means(newest(src / "cal_write" / "*" / "*_counter_collection.csv"))
     bench = json.loads((src / "bench_trace.json").read_text().strip().splitlines()[-1])
+    plan = bench.get("plan", "")
+    variant = bench["config"]["variant"]
+    if variant == "auto" and plan.startswith("auto -> "):      # what SPMV_AUTO resolved to
+        variant = plan.split("auto -> ")[1].split(":")[0]
 
     # calibration: k_stream<16,false> reads exactly 2^31 B (2^28 col_idx + 2^28 vals) and writes 2^26 B
     ck = next(k for k in cal_f if "k_stream<16, false>" in k)
@@ -62,12 +66,12 @@ def main():
         kernels[k] = {"launches": n, "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
                       "hbm_bytes_per_launch": int(round((2 * f_kib + w_kib) * 1024))}
     # the plan autotunes over several instantiations of k_adaptive: the timed one has the most launches
-    hot = ("k_panel(",) if bench["config"]["variant"] == "panel" else ("k_adaptive", "k_tiled16")
+    hot = ("k_panel(",) if variant == "panel" else ("k_adaptive", "k_tiled16", "k_tiled_mixed")
     dom = max((k for k in kernels if any(h in k for h in hot)), key=lambda k: kernels[k]["launches"])
     # the panel sweep covers the matrix in several launches of the same kernel ("launches=N" in the plan string):
     # scale the per-launch counters to one SpMV so they compare with the algorithmic bytes of one SpMV
     per_spmv = 1
-    if bench["config"]["variant"] == "panel" and "launches=" in bench.get("plan", ""):
+    if variant == "panel" and "launches=" in bench.get("plan", ""):
         per_spmv = int(bench["plan"].split("launches=")[1].split()[0])
     if per_spmv > 1:
         for key in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_per_launch"):
@@ -75,7 +79,7 @@ def main():
         kernels[dom]["note"] = f"counters scaled by {per_spmv}: one SpMV = {per_spmv} launches of this kernel"
     summary = {"tag": tag, "command": "python3 bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline"
                                       + (" " + " ".join(sys.argv[2:]) if len(sys.argv) > 2 else ""),
-               "workload": bench["config"]["workload"], "variant": bench["config"]["variant"],
+               "workload": bench["config"]["workload"], "variant": variant, "plan": plan,
                "calibration": {"kernel": ck, "known_read_bytes": int(known_read), "FETCH_SIZE_KiB": cal_f[ck][0],
                                "read_bytes_per_FETCH_KiB": round(read_factor * 1024, 2),
                                "read_correction_factor": round(read_factor, 4),
@@ -95,8 +99,9 @@ def main():
     band = 0
     if "band " in bench["config"]["workload"]:
         band = int(bench["config"]["workload"].split("band ")[1].split(")")[0])
-    tj[f"{bench['config']['variant']}:{wname}:band{band}"] = {
-        "hbm_bytes_per_launch": kernels[dom]["hbm_bytes_per_launch"], "kernel": dom, "profile": f"{tag}_pmc_summary.json"}
+    tj[f"{variant}:{wname}:band{band}"] = {
+        "hbm_bytes_per_launch": kernels[dom]["hbm_bytes_per_launch"], "kernel": dom, "profile": f"{tag}_pmc_summary.json",
+        "plan": plan}      # bench.py replays the figure only while its own plan string equals this one
     tfile.write_text(json.dumps(tj, indent=1))
     print(json.dumps({k: summary[k] for k in ("calibration", "dominant_kernel", "traffic_over_algorithmic")}, indent=1))
     print(open(dst / f"{tag}_kernel_stats.csv").read())
