@@ -293,7 +293,8 @@ static int plan_auto(spmv_csr &h, hipStream_t s)
     int rc = plan_adaptive(h, true, s);
     if (rc) return rc;
     const ChunkPlan &p = h.plan_tiled;
-    const bool little_staged = p.nchunks > 0 && 2 * (int64_t)p.staged_full < p.nchunks && 2 * (int64_t)p.nblk_chunks < p.nchunks;
+    const bool little_staged = p.nchunks > 0 && 2 * ((int64_t)p.staged_full + p.nsorted) < p.nchunks &&
+                               2 * (int64_t)p.nblk_chunks < p.nchunks;
     const bool x_beyond_l2 = h.cols * (int64_t)sizeof(float) > (4ll << 20);
     if (little_staged && x_beyond_l2) {
         rc = plan_panel(h, s);
@@ -433,11 +434,11 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
     switch (variant) {
         case SPMV_ADAPTIVE:  // chunk_lb read + carry written and re-read
             return (int64_t)(h->plan_adaptive.nchunks + 1) * 4 + (int64_t)h->plan_adaptive.nchunks * 8;
-        case SPMV_TILED:     // + the two window words per chunk, the chunk lists and the 16-bit offsets
+        case SPMV_TILED:     // + the two window words per chunk, the chunk lists, the 16-bit offsets and the sorted words
             return (int64_t)(h->plan_tiled.nchunks + 1) * 4 + (int64_t)h->plan_tiled.nchunks * 16 +
-                   (h->plan_tiled.d_col16 ? (int64_t)h->plan_tiled.nchunks * 4 +
-                                                (int64_t)h->plan_tiled.n16 * 2 * h->plan_tiled.block * kNnzPerThread
-                                          : 0) +
+                   ((h->plan_tiled.n16 || h->plan_tiled.nsorted) ? (int64_t)h->plan_tiled.nchunks * 4 : 0) +
+                   (int64_t)h->plan_tiled.n16 * 2 * h->plan_tiled.block * kNnzPerThread +
+                   (int64_t)h->plan_tiled.nsorted * 4 * h->plan_tiled.block * kNnzPerThread +
                    (int64_t)h->plan_tiled.nblk_chunks * 256 * 4;   // block lists: up to 256 ids per chunk that has one
         case SPMV_PANEL:     // tile_ptr; packed/pvals REPLACE col_idx/vals byte for byte
             return (int64_t)h->plan_panel.nblocks * (h->plan_panel.npanels + 1) * 4 + ((int64_t)h->plan_panel.nblocks + 1) * 4;
@@ -463,9 +464,9 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
     else if (!p) snprintf(buf, (size_t)n, "no plan");
     else if (!p->block) snprintf(buf, (size_t)n, "not planned");
     else
-        snprintf(buf, (size_t)n, "block=%d region=%d maxpass=%d chunks=%d staged_single=%d staged_full=%d col16_chunks=%d block_list_chunks=%d spanning_rows=%d persist=%d",
-                 p->block, p->region, p->maxpass, p->nchunks, p->staged_single, p->staged_full, p->n16, p->nblk_chunks,
-                 p->spanning_rows, p->persist ? 1 : 0);
+        snprintf(buf, (size_t)n, "block=%d region=%d maxpass=%d chunks=%d staged_single=%d staged_full=%d col16_chunks=%d sorted_chunks=%d block_list_chunks=%d spanning_rows=%d persist=%d model_cost=%.3f",
+                 p->block, p->region, p->maxpass, p->nchunks, p->staged_single, p->staged_full, p->n16, p->nsorted,
+                 p->nblk_chunks, p->spanning_rows, p->persist ? 1 : 0, p->model_cost);
     return SPMV_OK;
 }
 

@@ -31,6 +31,7 @@
 #include <atomic>
 #include <climits>
 #include <cstdlib>
+#include <cstring>
 #include "spmv_internal.hpp"
 
 namespace spmv {
@@ -96,7 +97,17 @@ __global__ void k_plan_chunks(int64_t rows, int nchunks, int chunk, const int32_
 constexpr int kOutsideBit = 1 << 30;
 constexpr int kCol16Bit = 1 << 29;   // the chunk's columns also exist as 16-bit offsets from w0 (plan.d_col16)
 constexpr int kBlockBit = 1 << 28;   // ... as 16-bit indices into a LIST of staged 256-column blocks (plan.d_blk)
-constexpr int kLenMask = kBlockBit - 1;
+constexpr int kSortedBit = 1 << 27;  // nothing is staged: the chunk gathers x in COLUMN order (plan.d_perm), see sorted_body
+constexpr int kLenMask = kSortedBit - 1;
+#ifndef SPMV_T_SORTED_FROM
+#define SPMV_T_SORTED_FROM (-1)   // -1: staged or sorted by modelled cost, per chunk
+#endif
+constexpr int kSortedFromDefault = SPMV_T_SORTED_FROM;
+// Sorted chunks: one 32-bit word per nonzero = position in the chunk (log2(chunk) bits, high) | column - w0 (the rest,
+// 18 bits: the plan's counting sort keeps one LDS counter per 128-byte line of the span).
+__host__ __device__ constexpr int sorted_pos_bits(int block) { return block == 1024 ? 14 : (block == 512 ? 13 : 12); }
+__host__ __device__ constexpr int sorted_col_bits(int) { return 18; }   // 8192 lines = 32 KiB of counters in the plan kernel
+static_assert(sorted_pos_bits(1024) + sorted_col_bits(1024) <= 32, "one word per nonzero");
 #ifndef SPMV_T_BLKBITS
 #define SPMV_T_BLKBITS 8
 #endif
@@ -104,10 +115,26 @@ constexpr int kBlkBits = SPMV_T_BLKBITS;
 constexpr int kBlkCols = 1 << kBlkBits;      // columns per staged block (256: one 1-KiB LDS-DMA piece per wave)
 constexpr int kBlkMax = 65536 / kBlkCols;    // blocks per chunk: 65 536 staged floats is what a 16-bit index reaches
 
+// Modelled time of one full chunk, in 1/1024 of the time a chunk of that size takes to stream 8 bytes per nonzero with
+// cache-resident gathers.  Fitted on one MI355X to c4 with bands of 8192 ... 200 000 columns and to c3, both workgroup
+// sizes, every chunk forced staged and forced sorted (tools/exp/r02_calibrate.json -> profiles/r02_plan_calibration.jsonl;
+// DESIGN.md section 4):
+//   staged, 16-bit columns                 0.77 + 0.107 per pass            (1 ... 7 passes, 512 and 1024 threads)
+//   staged, 32-bit columns (span >= 65536)  1.05 + 0.12  per pass
+//   sorted                                  1.05 + 1.75 (512 threads) | 1.45 (1024) x 128-byte lines of the span per nonzero
+//   sorted, <= 16 rows in the chunk         0.2 less: the inside of a long row whose columns ascend is an (almost)
+//                                           identity permutation -- the LDS scatter is conflict-free
+//   gathers from L2/fabric unsorted         3
+struct PlanCost {
+    int c16_base = 788, c16_pass = 110, c32_base = 1075, c32_pass = 123, sorted_base = 1075, sorted_line_512 = 1792,
+        sorted_line_1024 = 1485, sorted_few_rows = 205, unstaged = 3072;
+};
+
 __global__ __launch_bounds__(256) void k_plan_windows(int64_t nnz, int64_t cols, int nchunks, int chunk,
                                                       const int32_t *__restrict__ col_idx,
                                                       int32_t *__restrict__ win, int32_t *__restrict__ stats,
-                                                      int region, int maxpass)
+                                                      int region, int maxpass, int sorted_from, int sorted_span,
+                                                      PlanCost cost, const int32_t *__restrict__ lb)
 {
     __shared__ int s_min[4], s_max[4], s_cnt[4];
     __shared__ long long s_sum[4];
@@ -137,6 +164,37 @@ __global__ __launch_bounds__(256) void k_plan_windows(int64_t nnz, int64_t cols,
     for (int w = 0; w < 4; ++w) {  // every thread folds the four partials
         mn = w == 0 ? s_min[0] : (s_min[w] < mn ? s_min[w] : mn);
         mx = w == 0 ? s_max[0] : (s_max[w] > mx ? s_max[w] : mx);
+    }
+    // Staged or sorted?  Every staging pass re-reads `region` floats of x from L2 and costs a barrier pair and 16
+    // predicated LDS reads per lane; the sorted gather (sorted_body) touches every 128-byte line of the span about
+    // once, with no barrier, but streams 8 bytes per nonzero where a staged chunk with 16-bit columns streams 6.  The
+    // plan prices both for this chunk with the constants of PlanCost (fitted to measurements) and
+    // takes the cheaper; the sum of the chunk prices is how the plan compares workgroup sizes.  sorted_from = 0:
+    // never sort; > 0: sort from that many passes on, whatever the prices (tuning knob SPMV_SORTED_FROM).
+    {
+        const int w0_line = mn & ~31;
+        const int64_t span_l = (int64_t)mx + 1 - w0_line;
+        const int64_t span4 = (int64_t)mx + 1 - (mn & ~3);
+        const int64_t passes = (span4 + region - 1) / region;
+        const int lines = (int)((span_l + 31) >> 5);
+        const int cost_staged = passes > maxpass ? cost.unstaged
+                                : (span4 < 65536 ? cost.c16_base + cost.c16_pass * (int)passes
+                                                 : cost.c32_base + cost.c32_pass * (int)passes);
+        const int rows_here = lb[c + 1] - lb[c];
+        const int cost_sorted = cost.sorted_base + (int)((int64_t)(chunk >= 16384 ? cost.sorted_line_1024 : cost.sorted_line_512) * lines / chunk) -
+                                (rows_here <= 16 ? cost.sorted_few_rows : 0);
+        const bool eligible = sorted_from != 0 && n == chunk && span_l <= sorted_span;
+        const bool sort = eligible && (sorted_from > 0 ? span_l > (int64_t)region * (sorted_from - 1) : cost_sorted < cost_staged);
+        if (threadIdx.x == 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(stats + 4), (unsigned long long)(sort ? cost_sorted : cost_staged));
+        if (sort) {
+            if (threadIdx.x == 0) {
+                win[2 * c] = w0_line;
+                win[2 * c + 1] = kSortedBit;
+                atomicAdd(&stats[2], 1);
+            }
+            return;
+        }
     }
     const int w0_full = mn & ~3;
     const int64_t span = (int64_t)mx + 1 - w0_full;
@@ -657,30 +715,171 @@ __global__ __launch_bounds__(BLOCK, 8) void k_tiled16(int64_t rows, int64_t cols
                                 list, kRegion, blk);
 }
 
-// Both kinds of chunk in ONE launch: workgroups [0, n32) run the 32-bit body over list32 (the slow chunks -- wide
-// spans, outliers gathered from global memory -- start first), the others the 16-bit body over list16.  Two launches
+// ---------------------------------------------------------------------------
+// Sorted chunks.  A chunk whose column span is several LDS regions wide (a band of 65 536 columns; the inside of a
+// power-law row) used to stage the span slice by slice: every slice is region floats of L2 -> LDS traffic, a barrier
+// pair and 16 predicated LDS reads per lane.  Here the plan sorts the chunk's nonzeros by COLUMN once
+// (perm[k] = position in the chunk << 18 | column - w0, 4 bytes per nonzero read INSTEAD of col_idx) and the kernel
+// gathers x straight from L1/L2 in that order: the lanes of a gather instruction then touch a handful of
+// neighbouring 128-byte lines instead of 64 scattered ones (every line of the span is requested about once per chunk,
+// the same L2 traffic as staging it, without the passes).  The gathered x values are scattered through LDS to the
+// positions their nonzeros have in the row-major stream, where the lane that holds the VALUES of those positions
+// (read live from vals, original order: nothing is copied) picks them up, multiplies and leaves the products for
+// the same row reduction as everywhere else.  Same products, same order of every sum as the other bodies.
+template <int BLOCK>
+__device__ __forceinline__ void sorted_body(float *smem, ChunkShared<BLOCK> &sh, int bid, int64_t rows, int nrun,
+                                            const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ perm,
+                                            const float *__restrict__ vals, const float *__restrict__ x,
+                                            float *__restrict__ y, const int32_t *__restrict__ chunk_lb,
+                                            float *__restrict__ carry, const int32_t *__restrict__ win,
+                                            const int32_t *__restrict__ list)
+{
+    constexpr int kChunkT = chunk_of(BLOCK);
+    constexpr int kVec = kNnzPerThread / 4;
+    constexpr int kColBits = sorted_col_bits(BLOCK);
+    constexpr unsigned kColMask = (1u << kColBits) - 1u;
+
+    const int tid = threadIdx.x;
+    const int c = list[xcd_chunk(bid, nrun)];
+    const int64_t base = (int64_t)c * kChunkT;
+    const int64_t lim = base + kChunkT;
+    if (tid == 0) { sh.long_count = 0; sh.huge_count = 0; }
+    const int lb0 = chunk_lb[c], lb1 = chunk_lb[c + 1];
+    const int m = lb1 - lb0;
+    const float *xw = x + win[2 * c];
+
+    u4 pw[kVec];
+    f4 vv[kVec];
+    {
+        const u4 *p4 = reinterpret_cast<const u4 *>(perm + base);
+        const f4 *v4 = reinterpret_cast<const f4 *>(vals + base);
+#pragma unroll
+        for (int j = 0; j < kVec; ++j) pw[j] = __builtin_nontemporal_load(&p4[j * BLOCK + tid]);
+#pragma unroll
+        for (int j = 0; j < kVec; ++j) vv[j] = __builtin_nontemporal_load(&v4[j * BLOCK + tid]);
+    }
+    int32_t rb0 = 0, re0 = 0;
+    if (tid <= m) {
+        rb0 = row_ptr[tid == 0 ? lb0 : lb0 + tid - 1];
+        re0 = tid == 0 ? 0 : row_ptr[lb0 + tid];
+    }
+
+    // gather in column order, scatter to the row-major position of each nonzero
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+        float g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = xw[pw[j][q] & kColMask];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) smem[pad_idx((int)(pw[j][q] >> kColBits))] = g[q];
+    }
+    __syncthreads();
+    // this lane's values meet their x; the products take the same LDS words
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+        const int p0 = pad_idx((j * BLOCK + tid) * 4);
+        smem[p0] = vv[j][0] * smem[p0];
+        smem[p0 + 1] = vv[j][1] * smem[p0 + 1];
+        smem[p0 + 2] = vv[j][2] * smem[p0 + 2];
+        smem[p0 + 3] = vv[j][3] * smem[p0 + 3];
+    }
+    __syncthreads();
+    reduce_chunk<BLOCK, true>(smem, sh, tid, c, lb0, m, base, lim, row_ptr, y, carry, rb0, re0);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void k_sorted(int64_t rows, int nrun, const int32_t *__restrict__ row_ptr,
+                                                     const uint32_t *__restrict__ perm, const float *__restrict__ vals,
+                                                     const float *__restrict__ x, float *__restrict__ y,
+                                                     const int32_t *__restrict__ chunk_lb, float *__restrict__ carry,
+                                                     const int32_t *__restrict__ win, const int32_t *__restrict__ list)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ ChunkShared<BLOCK> sh;
+    sorted_body<BLOCK>(smem, sh, (int)blockIdx.x, rows, nrun, row_ptr, perm, vals, x, y, chunk_lb, carry, win, list);
+}
+
+// plan: counting sort of one chunk's nonzeros by the 128-byte line of x their column lies in (the order inside a line
+// does not matter: the gathers of a line coalesce whatever their order, and no arithmetic depends on it).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_plan_sorted(const int32_t *__restrict__ col_idx,
+                                                       const int32_t *__restrict__ win, uint32_t *__restrict__ perm)
+{
+    constexpr int kChunkT = chunk_of(BLOCK);
+    constexpr int kColBits = sorted_col_bits(BLOCK);
+    constexpr int kLines = 1 << (kColBits - 5);
+    constexpr int kPer = kLines / BLOCK;
+    static_assert(kLines % BLOCK == 0, "bins per thread");
+    __shared__ int hist[kLines];
+    __shared__ int part[BLOCK];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    if (!(win[2 * c + 1] & kSortedBit)) return;   // chunk-uniform
+    const int w0 = win[2 * c];
+    const int64_t base = (int64_t)c * kChunkT;
+    for (int i = tid; i < kLines; i += BLOCK) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < kChunkT; i += BLOCK) atomicAdd(&hist[(col_idx[base + i] - w0) >> 5], 1);
+    __syncthreads();
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) sum += hist[tid * kPer + k];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < BLOCK; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int v = hist[tid * kPer + k];
+        hist[tid * kPer + k] = run;
+        run += v;
+    }
+    __syncthreads();
+    for (int i = tid; i < kChunkT; i += BLOCK) {
+        const int off = col_idx[base + i] - w0;
+        const int d = atomicAdd(&hist[off >> 5], 1);
+        // sorted element d goes where lane d % BLOCK finds it as component q of its j-th 16-byte load, (j, q) =
+        // divmod(d / BLOCK, 4): the 64 lanes of ONE gather instruction then hold 64 CONSECUTIVE sorted elements (a
+        // few neighbouring lines), not elements four apart whose lines the other three components would ask for again
+        const int t = d % BLOCK, jq = d / BLOCK;
+        perm[base + ((jq >> 2) * BLOCK + t) * 4 + (jq & 3)] = ((unsigned)i << kColBits) | (unsigned)off;
+    }
+}
+
+// All kinds of chunk in ONE launch: workgroups [0, n32) run the 32-bit body over list32 (the slow chunks -- outliers
+// gathered from global memory, the ragged last chunk -- start first), the next nsorted the sorted body, the rest the
+// 16-bit body over list16.  Two launches
 // would each end with a partly idle chip (power-law rows: 1758 such chunks took 71 us after the 209 us of the rest).
 template <int BLOCK, bool BLOCKS>
-__global__ __launch_bounds__(BLOCK, 8) void k_tiled_mixed(int64_t rows, int64_t nnz, int64_t cols, int n32, int n16,
-                                                          const int32_t *__restrict__ row_ptr,
+__global__ __launch_bounds__(BLOCK, 8) void k_tiled_mixed(int64_t rows, int64_t nnz, int64_t cols, int n32, int nsorted,
+                                                          int n16, const int32_t *__restrict__ row_ptr,
                                                           const int32_t *__restrict__ col_idx,
                                                           const uint16_t *__restrict__ col16,
+                                                          const uint32_t *__restrict__ perm,
                                                           const float *__restrict__ vals,
                                                           const float *__restrict__ x, float *__restrict__ y,
                                                           const int32_t *__restrict__ chunk_lb,
                                                           float *__restrict__ carry,
                                                           const int32_t *__restrict__ win,
                                                           const int32_t *__restrict__ list32,
+                                                          const int32_t *__restrict__ list_sorted,
                                                           const int32_t *__restrict__ list16, int kRegion,
                                                           const int32_t *__restrict__ blk)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ ChunkShared<BLOCK> sh;
-    if ((int)blockIdx.x < n32)
-        adaptive_body<BLOCK, true, false>(smem, sh, (int)blockIdx.x, n32, rows, nnz, cols, 0, n32, row_ptr, col_idx, vals, x,
+    const int b = (int)blockIdx.x;
+    if (b < n32)
+        adaptive_body<BLOCK, true, false>(smem, sh, b, n32, rows, nnz, cols, 0, n32, row_ptr, col_idx, vals, x,
                                           y, chunk_lb, carry, win, list32, kRegion);
+    else if (b < n32 + nsorted)
+        sorted_body<BLOCK>(smem, sh, b - n32, rows, nsorted, row_ptr, perm, vals, x, y, chunk_lb, carry, win, list_sorted);
     else
-        tiled16_body<BLOCK, BLOCKS>(smem, sh, (int)blockIdx.x - n32, rows, cols, n16, row_ptr, col16, vals, x, y, chunk_lb,
+        tiled16_body<BLOCK, BLOCKS>(smem, sh, b - n32 - nsorted, rows, cols, n16, row_ptr, col16, vals, x, y, chunk_lb,
                                     carry, win, list16, kRegion, blk);
 }
 
@@ -813,17 +1012,34 @@ __global__ __launch_bounds__(BLOCK) void k_plan_col16(int64_t nnz, const int32_t
 __global__ void k_plan_unblock(int nchunks, int32_t *__restrict__ win)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < nchunks && (win[2 * c + 1] & kBlockBit)) win[2 * c + 1] = 0;
+    if (c >= nchunks) return;
+    const int wl = win[2 * c + 1];
+    if (wl & kBlockBit) win[2 * c + 1] = 0;
+    else if (wl & kCol16Bit) win[2 * c + 1] = wl & ~kCol16Bit;
 }
 
-// plan: chunk lists from the exclusive scan of flags: list16[pos[c]] = c, list32[c - pos[c]] = c
-__global__ void k_plan_lists(int nchunks, const int32_t *__restrict__ flags, const int32_t *__restrict__ pos,
-                             int32_t *__restrict__ list16, int32_t *__restrict__ list32)
+// plan: the kind of every chunk from its window word: f16[c] = has 16-bit columns, fs[c] = sorted
+__global__ void k_plan_kinds(int nchunks, const int32_t *__restrict__ win, int32_t *__restrict__ f16,
+                             int32_t *__restrict__ fs)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
-    if (flags[c]) list16[pos[c]] = c;
-    else list32[c - pos[c]] = c;
+    const int wl = win[2 * c + 1];
+    f16[c] = (wl & kCol16Bit) ? 1 : 0;
+    fs[c] = (!(wl & kCol16Bit) && (wl & kSortedBit)) ? 1 : 0;
+}
+
+// plan: chunk lists from the exclusive scans of the two flag arrays (p16, ps hold the scans, win the kinds)
+__global__ void k_plan_lists(int nchunks, const int32_t *__restrict__ win, const int32_t *__restrict__ p16,
+                             const int32_t *__restrict__ ps, int32_t *__restrict__ list16,
+                             int32_t *__restrict__ list_sorted, int32_t *__restrict__ list32)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const int wl = win[2 * c + 1];
+    if (wl & kCol16Bit) list16[p16[c]] = c;
+    else if (wl & kSortedBit) list_sorted[ps[c]] = c;
+    else list32[c - p16[c] - ps[c]] = c;
 }
 
 // rows that continue past their owner chunk: y[r] += carry[c+1] + carry[c+2] + ... in chunk order
@@ -870,11 +1086,14 @@ static void free_plan(ChunkPlan &p)
     if (p.d_col16) (void)hipFree(p.d_col16);
     if (p.d_list16) (void)hipFree(p.d_list16);
     if (p.d_list32) (void)hipFree(p.d_list32);
+    if (p.d_perm) (void)hipFree(p.d_perm);
+    if (p.d_list_sorted) (void)hipFree(p.d_list_sorted);
     if (p.d_blk) (void)hipFree(p.d_blk);
     p = ChunkPlan();
 }
 
 static int default_passes(int block) { return block == 1024 ? 12 : (block == 512 ? 4 : 2); }
+
 
 // chunk boundaries (+ column windows when `maxpass` > 0) for workgroups of `block` threads
 static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, ChunkPlan &p, int *single, int *full)
@@ -889,6 +1108,22 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
     // tuning knob SPMV_PERSIST=0|1, read when the plan is made (default 0: the persistent form
     // needs 80 VGPRs -> 6 waves/SIMD, and lost 7-40 % against 8 waves/SIMD one-shot workgroups)
     if (const char *e = getenv("SPMV_PERSIST")) p.persist = atoi(e) != 0;
+    // tuning knob SPMV_SORTED_FROM=n: chunks whose span needs n staging passes or more gather in column order
+    // instead (0 = never; default 3: measured)
+    p.sorted_from = windows && !p.persist ? kSortedFromDefault : 0;
+    if (const char *e = getenv("SPMV_SORTED_FROM")) {
+        const int v = atoi(e);
+        if (windows && !p.persist && v >= -1 && v <= 64) p.sorted_from = v;
+    }
+    PlanCost cost;
+    if (const char *e = getenv("SPMV_PLAN_COST")) {   // nine integers, the fields of PlanCost in order (calibration runs)
+        int v[9];
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) == 9) {
+            cost.c16_base = v[0]; cost.c16_pass = v[1]; cost.c32_base = v[2]; cost.c32_pass = v[3];
+            cost.sorted_base = v[4]; cost.sorted_line_512 = v[5]; cost.sorted_line_1024 = v[6]; cost.sorted_few_rows = v[7];
+            cost.unstaged = v[8];
+        }
+    }
     const int chunk = chunk_of(block);
     p.nchunks = (int)((h.nnz + chunk - 1) / chunk);
     if (single) *single = 0;
@@ -915,18 +1150,23 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
         p.spanning_rows = spans;
     }
     if (windows) {
-        // [2*nchunks] windows + 2 words of statistics
-        SPMV_HIP_TRY(hipMalloc((void **)&p.d_win, sizeof(int32_t) * (2 * (size_t)p.nchunks + 2)));
+        // [2*nchunks] windows + 6 words of statistics (the last two: the 64-bit sum of the modelled chunk costs)
+        SPMV_HIP_TRY(hipMalloc((void **)&p.d_win, sizeof(int32_t) * (2 * (size_t)p.nchunks + 6)));
         int32_t *d_stats = p.d_win + 2 * (size_t)p.nchunks;
-        SPMV_HIP_TRY(hipMemsetAsync(d_stats, 0, 2 * sizeof(int32_t), s));
+        SPMV_HIP_TRY(hipMemsetAsync(d_stats, 0, 6 * sizeof(int32_t), s));
         hipLaunchKernelGGL(k_plan_windows, dim3(p.nchunks), dim3(256), 0, s, h.nnz, h.cols, p.nchunks, chunk,
-                           h.d_col_idx, p.d_win, d_stats, p.region, maxpass);
+                           h.d_col_idx, p.d_win, d_stats, p.region, maxpass, p.sorted_from, 1 << sorted_col_bits(block),
+                           cost, p.d_lb);
         if ((rc = check_launch("k_plan_windows"))) return rc;
-        int32_t stats[2] = {0, 0};
+        int32_t stats[6] = {0, 0, 0, 0, 0, 0};
         SPMV_HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, s));
         SPMV_HIP_TRY(hipStreamSynchronize(s));
         p.staged_single = stats[0];
         p.staged_full = stats[1];
+        p.nsorted_marked = stats[2];
+        uint64_t total_cost;
+        memcpy(&total_cost, &stats[4], sizeof total_cost);
+        p.model_cost = (double)total_cost * (double)chunk / 1024.0 / (double)(h.nnz > 0 ? h.nnz : 1);
         if (single) *single = stats[0];
         if (full) *full = stats[1];
     }
@@ -956,8 +1196,6 @@ static int build_col16(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
     SPMV_HIP_TRY(pos.alloc((size_t)p.nchunks));
     SPMV_HIP_TRY(total.alloc(1));
     SPMV_HIP_TRY(hipMalloc((void **)&p.d_col16, sizeof(uint16_t) * chunk * (size_t)p.nchunks));
-    SPMV_HIP_TRY(hipMalloc((void **)&p.d_list16, sizeof(int32_t) * (size_t)p.nchunks));
-    SPMV_HIP_TRY(hipMalloc((void **)&p.d_list32, sizeof(int32_t) * (size_t)p.nchunks));
     // block lists (kBlkMax ids per chunk): SPMV_BLOCKS=0 keeps contiguous windows only
     bool want_blocks = true;
     if (const char *e = getenv("SPMV_BLOCKS")) want_blocks = atoi(e) != 0;
@@ -988,33 +1226,85 @@ static int build_col16(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
     if ((rc = run(p.d_blk, 0))) return rc;
     SPMV_HIP_TRY(hipMemcpyAsync(pos.p, flags.p, sizeof(int32_t) * (size_t)p.nchunks, hipMemcpyDeviceToDevice, s));
     if ((rc = exclusive_scan_i32(pos.p, p.nchunks, total.p, s))) return rc;
-    hipLaunchKernelGGL(k_plan_lists, dim3((p.nchunks + 255) / 256), dim3(256), 0, s, p.nchunks, flags.p, pos.p, p.d_list16,
-                       p.d_list32);
-    if ((rc = check_launch("k_plan_lists"))) return rc;
     int32_t n16 = 0, nb = 0;
     SPMV_HIP_TRY(hipMemcpyAsync(&n16, total.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SPMV_HIP_TRY(hipMemcpyAsync(&nb, nblk.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SPMV_HIP_TRY(hipStreamSynchronize(s));
-    p.n16 = n16;
     p.nblk_chunks = nb;
     if (nb == 0 && p.d_blk) { (void)hipFree(p.d_blk); p.d_blk = nullptr; }
-    if (2 * (int64_t)n16 < p.nchunks) {  // too few eligible chunks to pay for the 2-byte copy: 32-bit path
-        p.n16 = 0;
-        if (p.nblk_chunks > 0) {
-            hipLaunchKernelGGL(k_plan_unblock, dim3((p.nchunks + 255) / 256), dim3(256), 0, s, p.nchunks, p.d_win);
-            if ((rc = check_launch("k_plan_unblock"))) return rc;
-            SPMV_HIP_TRY(hipStreamSynchronize(s));
-        }
+    // too few eligible chunks to pay for the 2-byte copy (counting the sorted chunks with them: those read 4 bytes of
+    // perm instead of col_idx either way): back to 32-bit columns
+    if (2 * ((int64_t)n16 + p.nsorted_marked) < p.nchunks) {
+        hipLaunchKernelGGL(k_plan_unblock, dim3((p.nchunks + 255) / 256), dim3(256), 0, s, p.nchunks, p.d_win);
+        if ((rc = check_launch("k_plan_unblock"))) return rc;
+        SPMV_HIP_TRY(hipStreamSynchronize(s));
         p.nblk_chunks = 0;
         (void)hipFree(p.d_col16); p.d_col16 = nullptr;
-        (void)hipFree(p.d_list16); p.d_list16 = nullptr;
-        (void)hipFree(p.d_list32); p.d_list32 = nullptr;
         if (p.d_blk) { (void)hipFree(p.d_blk); p.d_blk = nullptr; }
     }
     return SPMV_OK;
 }
 
+template <int BLOCK>
+static int launch_plan_sorted(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_plan_sorted<BLOCK>), dim3(p.nchunks), dim3(BLOCK), 0, s, h.d_col_idx, p.d_win, p.d_perm);
+    return check_launch("k_plan_sorted");
+}
+
+// The last step of a TILED plan: the column-sorted words of the chunks marked kSortedBit, and the three chunk lists
+// (16-bit / sorted / 32-bit) the launch walks.
+static int build_lists(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
+{
+    if (p.d_list16) { (void)hipFree(p.d_list16); p.d_list16 = nullptr; }
+    if (p.d_list32) { (void)hipFree(p.d_list32); p.d_list32 = nullptr; }
+    if (p.d_list_sorted) { (void)hipFree(p.d_list_sorted); p.d_list_sorted = nullptr; }
+    if (p.d_perm) { (void)hipFree(p.d_perm); p.d_perm = nullptr; }
+    p.n16 = p.nsorted = 0;
+    if (p.nchunks == 0 || !p.d_win || p.persist) return SPMV_OK;
+    int rc;
+    DevPtr<int32_t> f16, fs, t16, ts;
+    SPMV_HIP_TRY(f16.alloc((size_t)p.nchunks));
+    SPMV_HIP_TRY(fs.alloc((size_t)p.nchunks));
+    SPMV_HIP_TRY(t16.alloc(1));
+    SPMV_HIP_TRY(ts.alloc(1));
+    const unsigned g = (unsigned)((p.nchunks + 255) / 256);
+    hipLaunchKernelGGL(k_plan_kinds, dim3(g), dim3(256), 0, s, p.nchunks, p.d_win, f16.p, fs.p);
+    if ((rc = check_launch("k_plan_kinds"))) return rc;
+    if ((rc = exclusive_scan_i32(f16.p, p.nchunks, t16.p, s))) return rc;
+    if ((rc = exclusive_scan_i32(fs.p, p.nchunks, ts.p, s))) return rc;
+    int32_t n16 = 0, ns = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&n16, t16.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipMemcpyAsync(&ns, ts.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    p.n16 = n16;
+    p.nsorted = ns;
+    if (n16 == 0 && ns == 0) return SPMV_OK;   // every chunk runs the 32-bit body: no lists needed
+    SPMV_HIP_TRY(hipMalloc((void **)&p.d_list16, sizeof(int32_t) * (size_t)(n16 ? n16 : 1)));
+    SPMV_HIP_TRY(hipMalloc((void **)&p.d_list_sorted, sizeof(int32_t) * (size_t)(ns ? ns : 1)));
+    SPMV_HIP_TRY(hipMalloc((void **)&p.d_list32, sizeof(int32_t) * (size_t)(p.nchunks - n16 - ns ? p.nchunks - n16 - ns : 1)));
+    hipLaunchKernelGGL(k_plan_lists, dim3(g), dim3(256), 0, s, p.nchunks, p.d_win, f16.p, fs.p, p.d_list16, p.d_list_sorted,
+                       p.d_list32);
+    if ((rc = check_launch("k_plan_lists"))) return rc;
+    if (ns > 0) {
+        SPMV_HIP_TRY(hipMalloc((void **)&p.d_perm, sizeof(uint32_t) * (size_t)chunk_of(p.block) * (size_t)p.nchunks));
+        if (p.block == 256) rc = launch_plan_sorted<256>(h, p, s);
+        else if (p.block == 512) rc = launch_plan_sorted<512>(h, p, s);
+        else rc = launch_plan_sorted<1024>(h, p, s);
+        if (rc) return rc;
+    }
+    SPMV_HIP_TRY(hipStreamSynchronize(s));   // the scans' temporaries are freed on return
+    return SPMV_OK;
+}
+
 int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s);
+
+// 16-bit column copy (where it pays) and the chunk lists of the plan in h.plan_tiled
+static int finish_tiled(spmv_csr &h, bool col16, hipStream_t s)
+{
+    int rc = col16 ? build_col16(h, h.plan_tiled, s) : SPMV_OK;
+    return rc ? rc : build_lists(h, h.plan_tiled, s);
+}
 
 int plan_tiled_with(spmv_csr &h, int block, int maxpass, bool col16, hipStream_t s)
 {
@@ -1024,6 +1314,7 @@ int plan_tiled_with(spmv_csr &h, int block, int maxpass, bool col16, hipStream_t
     }
     int rc = build_plan(h, block, maxpass, s, h.plan_tiled, nullptr, nullptr);
     if (rc == SPMV_OK && col16) rc = build_col16(h, h.plan_tiled, s);
+    if (rc == SPMV_OK) rc = build_lists(h, h.plan_tiled, s);
     if (rc) free_plan(h.plan_tiled);
     return rc;
 }
@@ -1053,7 +1344,7 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
     if (forced_pass < 1 || forced_pass > 64) forced_pass = 0;
     if (forced) {
         int rc = build_plan(h, forced, forced_pass ? forced_pass : default_passes(forced), s, h.plan_tiled, nullptr, nullptr);
-        return rc ? rc : build_col16(h, h.plan_tiled, s);
+        return rc ? rc : finish_tiled(h, true, s);
     }
 
     // The default plan is a pure function of the matrix (chunk statistics below): two handles of the same matrix --
@@ -1063,22 +1354,26 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
     bool autotune = false;
     if (const char *e = getenv("SPMV_AUTOTUNE")) autotune = atoi(e) != 0 && h.nnz >= (1 << 20);
     if (!autotune) {
-        // Heuristic: the smallest workgroup whose LDS region holds the whole column span of >= 90 %
-        // of the chunks in ONE pass (same LDS bytes and waves per CU for all three, but a larger
-        // workgroup pays more per barrier); failing that, 1024 threads with multi-pass staging when
-        // that covers at least half of the chunks; otherwise 256 threads (global gathers).
+        // The smallest workgroup whose LDS region holds the whole column span of >= 90 % of the chunks in ONE pass
+        // (same LDS bytes and waves per CU for all three, but a larger workgroup pays more per barrier).  Failing
+        // that, 512 threads: the chunks whose span needs three passes or more gather in column order anyway (sorted
+        // chunks: no passes), and what is left stages in one or two.
         const int cands[3] = {256, 512, 1024};
-        int full1024 = 0;
         for (int k = 0; k < 3; ++k) {
             int single = 0, full = 0;
             int rc = build_plan(h, cands[k], default_passes(cands[k]), s, h.plan_tiled, &single, &full);
             if (rc) return rc;
-            if (h.plan_tiled.nchunks == 0 || single >= 0.9 * h.plan_tiled.nchunks) return build_col16(h, h.plan_tiled, s);
-            full1024 = full;
+            if (h.plan_tiled.nchunks == 0 || single >= 0.9 * h.plan_tiled.nchunks) return finish_tiled(h, true, s);
         }
-        if (full1024 >= 0.5 * h.plan_tiled.nchunks) return build_col16(h, h.plan_tiled, s);
-        int rc = build_plan(h, 256, default_passes(256), s, h.plan_tiled, nullptr, nullptr);
-        return rc ? rc : build_col16(h, h.plan_tiled, s);
+        // no workgroup size stages (nearly) everything in one pass: compare the modelled cost of 512 threads / 8
+        // passes and 1024 / 12 (a wide band gains from the larger chunk: more nonzeros per line of x; the inside of a
+        // power-law row does not, and the larger workgroup pays more per barrier: 3 % handicap)
+        int rc = build_plan(h, 1024, 12, s, h.plan_tiled, nullptr, nullptr);
+        if (rc) return rc;
+        const double cost1024 = h.plan_tiled.model_cost * 1.03;
+        if ((rc = build_plan(h, 512, 8, s, h.plan_tiled, nullptr, nullptr))) return rc;
+        if (cost1024 < h.plan_tiled.model_cost && (rc = build_plan(h, 1024, 12, s, h.plan_tiled, nullptr, nullptr))) return rc;
+        return finish_tiled(h, true, s);
     }
 
     // Autotune (the default for real sizes): the best (workgroup size, pass budget) depends on how the
@@ -1097,7 +1392,7 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
             int single = 0, full = 0;
             int rc0 = build_plan(h, c.block, c.maxpass, s, h.plan_tiled, &single, &full);
             if (rc0) return rc0;
-            if (h.plan_tiled.nchunks == 0 || full > 0) { any = true; break; }
+            if (h.plan_tiled.nchunks == 0 || full > 0 || h.plan_tiled.nsorted_marked > 0) { any = true; break; }
         }
         if (!any) {
             // no contiguous span fits -- but a few column clusters far apart (a big 3-D stencil) fit as block lists
@@ -1148,6 +1443,7 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
                 if ((rc = build_col16(h, p, s))) break;
                 if (!p.d_col16) break;  // nothing eligible: same configuration as just timed
             }
+            if ((rc = build_lists(h, p, s))) break;
             float ms = 0.0f;
             if ((rc = time_plan(3, 2, ms))) break;
             Pick cur;
@@ -1168,7 +1464,7 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
         Pick *both[2] = {&best, &second};
         for (Pick *q : both) {
             if ((rc = build_plan(h, q->block, q->maxpass, s, h.plan_tiled, nullptr, nullptr))) break;
-            if (q->narrow && (rc = build_col16(h, h.plan_tiled, s))) break;
+            if ((rc = finish_tiled(h, q->narrow != 0, s))) break;
             if ((rc = time_plan(4, 4, q->ms))) break;
             if (getenv("SPMV_AUTOTUNE_LOG"))
                 fprintf(stderr, "[spmv autotune] rematch block=%d maxpass=%d col16=%d: %.4f ms\n", q->block, q->maxpass,
@@ -1182,7 +1478,7 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
     if (!best.set) return SPMV_OK;  // no nonzeros: the (empty) plan built last stands
     // rebuild the winner (plans are cheap next to the trials)
     if ((rc = build_plan(h, best.block, best.maxpass, s, h.plan_tiled, nullptr, nullptr))) return rc;
-    return best.narrow ? build_col16(h, h.plan_tiled, s) : SPMV_OK;
+    return finish_tiled(h, best.narrow != 0, s);
 }
 
 void destroy_plans(spmv_csr &h)
@@ -1244,10 +1540,10 @@ static int launch_mixed_t(const spmv_csr &h, const ChunkPlan &p, const float *x,
     const size_t lds = sizeof(float) * (size_t)p.region;
     static LdsOptIn optin;
     if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_tiled_mixed<BLOCK, BLOCKS>), h.device, (int)lds)) return rc;
-    const int n32 = p.nchunks - p.n16;
+    const int n32 = p.nchunks - p.n16 - p.nsorted;
     hipLaunchKernelGGL((k_tiled_mixed<BLOCK, BLOCKS>), dim3(p.nchunks), dim3(BLOCK), lds, s, h.rows, h.nnz, h.cols, n32,
-                       p.n16, h.d_row_ptr, h.d_col_idx, p.d_col16, h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, p.d_list32,
-                       p.d_list16, p.region, p.d_blk);
+                       p.nsorted, p.n16, h.d_row_ptr, h.d_col_idx, p.d_col16, p.d_perm, h.d_vals, x, y, p.d_lb, p.d_carry,
+                       p.d_win, p.d_list32, p.d_list_sorted, p.d_list16, p.region, p.d_blk);
     return check_launch("k_tiled_mixed");
 }
 
@@ -1257,13 +1553,25 @@ static int launch_mixed(const spmv_csr &h, const ChunkPlan &p, const float *x, f
     return p.nblk_chunks > 0 ? launch_mixed_t<BLOCK, true>(h, p, x, y, s) : launch_mixed_t<BLOCK, false>(h, p, x, y, s);
 }
 
+template <int BLOCK>
+static int launch_sorted(const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
+{
+    const size_t lds = sizeof(float) * (size_t)p.region;
+    static LdsOptIn optin;
+    if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_sorted<BLOCK>), h.device, (int)lds)) return rc;
+    hipLaunchKernelGGL((k_sorted<BLOCK>), dim3(p.nsorted), dim3(BLOCK), lds, s, h.rows, p.nsorted, h.d_row_ptr, p.d_perm,
+                       h.d_vals, x, y, p.d_lb, p.d_carry, p.d_win, p.d_list_sorted);
+    return check_launch("k_sorted");
+}
+
 template <int BLOCK, bool TILED>
 static int launch_either(bool persist, const spmv_csr &h, const ChunkPlan &p, const float *x, float *y, hipStream_t s)
 {
     if constexpr (TILED) {
-        if (!persist && p.d_col16) {
-            // every chunk has 16-bit columns: the lean kernel; otherwise both kinds in one launch
+        if (!persist && (p.n16 > 0 || p.nsorted > 0)) {
+            // every chunk has 16-bit columns: the lean kernel; otherwise all kinds in one launch
             if (p.n16 == p.nchunks) return launch_tiled16<BLOCK>(h, p, x, y, s);
+            if (p.nsorted == p.nchunks) return launch_sorted<BLOCK>(h, p, x, y, s);
             return launch_mixed<BLOCK>(h, p, x, y, s);
         }
     }
@@ -1291,7 +1599,7 @@ int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hip
     int rc;
     // a tiled plan that stages nothing runs the plain kernel (same chunks; it keeps the row-bound prefetch the
     // 32-bit tiled form has no registers for)
-    const bool nothing_staged = tiled && p.block == 256 && p.staged_full == 0 && !p.d_col16;
+    const bool nothing_staged = tiled && p.block == 256 && p.staged_full == 0 && p.n16 == 0 && p.nsorted == 0;
     if (!tiled || nothing_staged) rc = launch_either<256, false>(persist, h, p, x, y, s);
     else if (p.block == 256) rc = launch_either<256, true>(persist, h, p, x, y, s);
     else if (p.block == 512) rc = launch_either<512, true>(persist, h, p, x, y, s);

@@ -67,8 +67,15 @@ struct ChunkPlan {
     // 16-bit columns (TILED): chunks whose span is fully staged also carry col - w0 as uint16
     uint16_t *d_col16 = nullptr;   // [nchunks * chunk], lane layout of k_tiled16
     int32_t *d_list16 = nullptr;   // [n16] chunks run by k_tiled16
-    int32_t *d_list32 = nullptr;   // [nchunks - n16] the others, run by k_adaptive
+    int32_t *d_list32 = nullptr;   // [nchunks - n16 - nsorted] the others, run by the 32-bit body
     int n16 = 0;
+    // sorted chunks (TILED): spans of several LDS regions gather x in column order instead of staging it
+    uint32_t *d_perm = nullptr;        // [nchunks * chunk] position << 18 | column - w0, read INSTEAD of col_idx
+    int32_t *d_list_sorted = nullptr;  // [nsorted]
+    int nsorted = 0;                   // chunks run by the sorted body
+    int nsorted_marked = 0;            // chunks the window pass marked (a few may still switch to a block list)
+    int sorted_from = 0;               // -1: sorted where the modelled cost is lower; 0: never; n: from n passes on
+    double model_cost = 0.0;           // modelled time per nonzero of this plan (PlanCost units; compares block sizes)
     int32_t *d_blk = nullptr;      // [64 * nchunks] ids of the staged 1024-column blocks of the chunks that use a list
     int nblk_chunks = 0;           // how many chunks do
     int maxpass = 0;

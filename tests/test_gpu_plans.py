@@ -173,3 +173,33 @@ def test_dense_workspace_entry_and_cross_stream_handoff(pkg, oracle, gpu):
     torch.cuda.synchronize()
     assert_close_to_oracle(ya.cpu().numpy(), y64, mag, "dense mode 2, stream 1")
     assert_close_to_oracle(yb.cpu().numpy(), y64, mag, "dense mode 3, stream 2")
+
+
+# ---- sorted chunks: x gathered in column order instead of staged slice by slice -----------------------------------
+@pytest.mark.parametrize("name,band,scale", [("c4", 65536, 1 / 16), ("c3", 8192, 1 / 8), ("c4", 8192, 1 / 32)])
+@pytest.mark.parametrize("block", [256, 512, 1024])
+def test_sorted_chunks_reproduce_the_staged_result_bit_for_bit(pkg, oracle, gpu, monkeypatch, name, band, scale, block):
+    """The sorted body fetches the same x values and leaves the same products in the same LDS words as the staged
+    bodies, so for one workgroup size y must not change by a single bit whether a chunk is staged (SPMV_SORTED_FROM=0),
+    sorted from three passes on (the default) or always sorted (=1) -- and must match the oracle."""
+    capi = pkg.capi
+    w = pkg.workloads.config(name, band=band, scale=scale)
+    prob = synth_problem(pkg, oracle, gpu, w)
+    y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+    ys, descs = {}, {}
+    for sf in ("0", "3", "1", "-1"):
+        monkeypatch.setenv("SPMV_SORTED_FROM", sf)
+        prob.A.plan_set(capi.TILED, [capi.TILED, block, 8, 1, 0, 0, 0, 0])
+        ys[sf] = prob.run(capi.TILED)
+        descs[sf] = prob.A.plan_describe(capi.TILED)
+        assert_close_to_oracle(ys[sf], y64, mag, f"{w.name} sorted_from={sf}: {descs[sf]}")
+    assert " sorted_chunks=0 " in descs["0"]
+    n_chunks = int(descs["1"].split("chunks=")[1].split()[0])
+    n_sorted = int(descs["1"].split("sorted_chunks=")[1].split()[0])
+    # all full chunks but those whose span exceeds the 18-bit column field (the tail of a 65 536-long power-law row
+    # next to short rows) or that found a block list
+    assert n_sorted >= 0.95 * (n_chunks - 1 - int(descs["1"].split("block_list_chunks=")[1].split()[0])), descs["1"]
+    assert np.array_equal(ys["0"].view(np.uint32), ys["1"].view(np.uint32))
+    assert np.array_equal(ys["0"].view(np.uint32), ys["3"].view(np.uint32))
+    assert np.array_equal(ys["0"].view(np.uint32), ys["-1"].view(np.uint32))      # the default: sorted where modelled cheaper
+    prob.A.close()
