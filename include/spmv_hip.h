@@ -222,6 +222,24 @@ SPMV_API int spmv_tcsr_run(const spmv_tcsr_t *h, const float *d_x, float *d_y, v
 SPMV_API int spmv_tcsr_run_host(const spmv_tcsr_t *h, const float *x_host, float *y_host, float *kernel_ms);
 SPMV_API int spmv_tcsr_destroy(spmv_tcsr_t *h);
 
+/* ---- the reference's bitmap formats of its wsp / awsp / awsp_ref launchers (density > 1/32) -------------------
+ * replaces: WSPMatrix (src/wsp.cpp:3-40) + wsp_kernel_v0/v1 (src/kernels/wsp.cu:4-138),
+ *           AWSPMatrix (src/awsp.cpp:3-49) + awsp_kernel_v0/1/2 (src/kernels/awsp.cu:5-317),
+ *           AWSPRefMatrix (src/awsp_ref.cpp:4-58) + awsp_ref_kernel / wsp_sm_kernel (awsp_ref.cu:6-185, wsp_sm.cu:6-211).
+ * The arrays are the reference's, bit for bit (built on the device from the dense matrix); the multiply is re-derived
+ * for 64-lane wavefronts (64-bit word pairs, __popcll ranks, running value offsets, the reference's x == 0 skip).
+ * M and N must be multiples of 32.  stats[4] = what the reference classes expose: WSP {nz_max_m, nz_max_n, 0, 0},
+ * AWSP {nz_bk_max_, 0, 0, 0}, AWSPRef warp_nz_offset_[0..3]. */
+enum spmv_bitmap_format { SPMV_FMT_WSP = 0, SPMV_FMT_AWSP = 1, SPMV_FMT_AWSP_REF = 2, SPMV_FMT_COUNT = 3 };
+typedef struct spmv_bitmap spmv_bitmap_t;
+SPMV_API int spmv_bitmap_from_dense_host(int format, int M, int N, const float *A_host, void *stream, spmv_bitmap_t **out);
+SPMV_API int spmv_bitmap_from_dense_device(int format, int M, int N, const float *d_A, void *stream, spmv_bitmap_t **out);
+SPMV_API int spmv_bitmap_sizes(const spmv_bitmap_t *h, int64_t *n_bitmaps, int64_t *n_vals, int32_t stats[4]);
+SPMV_API int spmv_bitmap_download(const spmv_bitmap_t *h, uint32_t *bitmaps, float *vals);
+SPMV_API int spmv_bitmap_run(const spmv_bitmap_t *h, const float *d_x, float *d_y, void *stream);
+SPMV_API int spmv_bitmap_run_host(const spmv_bitmap_t *h, const float *x_host, float *y_host, float *kernel_ms);
+SPMV_API int spmv_bitmap_destroy(spmv_bitmap_t *h);
+
 /* ---- synthetic CSR of stated (rows, cols, nnz) ---------------------------
  * Counter-based generator (DESIGN.md "Synthetic workloads"): element k of
  * global row r is a pure function of (seed, r, k, row length, band), so the

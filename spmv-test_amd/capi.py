@@ -58,6 +58,13 @@ SIGNATURES = {
     "spmv_tcsr_run": (C.c_int, [_H, _f32p, _f32p, _vp]),
     "spmv_tcsr_run_host": (C.c_int, [_H, _f32p, _f32p, C.POINTER(C.c_float)]),
     "spmv_tcsr_destroy": (C.c_int, [_H]),
+    "spmv_bitmap_from_dense_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _f32p, _vp, _HP]),
+    "spmv_bitmap_from_dense_device": (C.c_int, [C.c_int, C.c_int, C.c_int, _f32p, _vp, _HP]),
+    "spmv_bitmap_sizes": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "spmv_bitmap_download": (C.c_int, [_H, _i32p, _f32p]),
+    "spmv_bitmap_run": (C.c_int, [_H, _f32p, _f32p, _vp]),
+    "spmv_bitmap_run_host": (C.c_int, [_H, _f32p, _f32p, C.POINTER(C.c_float)]),
+    "spmv_bitmap_destroy": (C.c_int, [_H]),
     "spmv_synth_fill": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                   _i32p, _i32p, _f32p, _vp]),
     "spmv_synth_x": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, _f32p, _vp]),
@@ -282,6 +289,65 @@ class TcsrMatrix:
     def close(self) -> None:
         if self._h:
             check(lib().spmv_tcsr_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+BITMAP_FORMATS = {"wsp": 0, "awsp": 1, "awsp_ref": 2}      # enum spmv_bitmap_format
+
+
+class BitmapMatrix:
+    """Owner of one ``spmv_bitmap_t``: the reference's WSP / AWSP / AWSPRef format (wsp.cpp, awsp.cpp,
+    awsp_ref.cpp) on the device."""
+
+    def __init__(self, handle: int, fmt: str, M: int, N: int):
+        self._h = C.c_void_p(handle)
+        self.fmt, self.M, self.N = fmt, M, N
+        a, b = C.c_int64(), C.c_int64()
+        st = (C.c_int32 * 4)()
+        check(lib().spmv_bitmap_sizes(self._h, C.byref(a), C.byref(b), st))
+        self.n_bitmaps, self.n_vals, self.stats = a.value, b.value, list(st)
+
+    @classmethod
+    def from_dense_host(cls, fmt: str, A):
+        import numpy as np
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        M, N = A.shape
+        h = C.c_void_p()
+        check(lib().spmv_bitmap_from_dense_host(BITMAP_FORMATS[fmt], M, N, _ptr(A), 0, C.byref(h)))
+        return cls(h.value, fmt, M, N)
+
+    @classmethod
+    def from_dense_device(cls, fmt: str, A):
+        M, N = A.shape
+        h = C.c_void_p()
+        check(lib().spmv_bitmap_from_dense_device(BITMAP_FORMATS[fmt], M, N, _ptr(A), _stream_handle(), C.byref(h)))
+        return cls(h.value, fmt, M, N)
+
+    def download(self):
+        import numpy as np
+        bm = np.empty(self.n_bitmaps, np.uint32)
+        va = np.empty(self.n_vals, np.float32)
+        check(lib().spmv_bitmap_download(self._h, _ptr(bm), _ptr(va)))
+        return bm, va
+
+    def run(self, x, y, stream=None) -> None:
+        assert x.numel() >= self.M and y.numel() >= self.N
+        check(lib().spmv_bitmap_run(self._h, _ptr(x), _ptr(y), _stream_handle(stream)))
+
+    def run_host(self, x, y) -> float:
+        ms = C.c_float()
+        check(lib().spmv_bitmap_run_host(self._h, _ptr(x), _ptr(y), C.byref(ms)))
+        return ms.value
+
+    def close(self) -> None:
+        if self._h:
+            check(lib().spmv_bitmap_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -651,6 +651,89 @@ int spmv_tcsr_destroy(spmv_tcsr_t *h)
     return SPMV_OK;
 }
 
+static int bitmap_check_dims(int format, int M, int N, const void *A, const void *out)
+{
+    if (format < 0 || format >= SPMV_FMT_COUNT) { set_error("spmv_bitmap_from_dense: unknown format %d", format); return SPMV_ERR_VARIANT; }
+    if (!out || M < 0 || N < 0 || (M % 32) || (N % 32) || (!A && (int64_t)M * N > 0) || (int64_t)M * N >= (1LL << 36)) {
+        set_error("spmv_bitmap_from_dense: M and N must be non-negative multiples of 32 (got %d x %d)", M, N);
+        return SPMV_ERR_INVALID;
+    }
+    return require_device();
+}
+
+int spmv_bitmap_from_dense_device(int format, int M, int N, const float *d_A, void *stream, spmv_bitmap_t **out)
+{
+    int rc = bitmap_check_dims(format, M, N, d_A, out);
+    if (rc) return rc;
+    return bitmap_from_dense(format, M, N, d_A, (hipStream_t)stream, out);
+}
+
+int spmv_bitmap_from_dense_host(int format, int M, int N, const float *A_host, void *stream, spmv_bitmap_t **out)
+{
+    int rc = bitmap_check_dims(format, M, N, A_host, out);
+    if (rc) return rc;
+    DevBuf dA;
+    const size_t bytes = sizeof(float) * (size_t)M * (size_t)N;
+    SPMV_HIP_TRY(dA.alloc(bytes));
+    SPMV_HIP_TRY(hipMemcpyAsync(dA.p, A_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    rc = bitmap_from_dense(format, M, N, (const float *)dA.p, (hipStream_t)stream, out);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    return rc;
+}
+
+int spmv_bitmap_sizes(const spmv_bitmap_t *h, int64_t *n_bitmaps, int64_t *n_vals, int32_t stats[4])
+{
+    if (!h) { set_error("spmv_bitmap_sizes: null handle"); return SPMV_ERR_INVALID; }
+    bitmap_info(*h, nullptr, nullptr, nullptr, n_bitmaps, n_vals, stats);
+    return SPMV_OK;
+}
+
+int spmv_bitmap_download(const spmv_bitmap_t *h, uint32_t *bitmaps, float *vals)
+{
+    if (!h) { set_error("spmv_bitmap_download: null handle"); return SPMV_ERR_INVALID; }
+    return bitmap_download(*h, bitmaps, vals);
+}
+
+int spmv_bitmap_run(const spmv_bitmap_t *h, const float *d_x, float *d_y, void *stream)
+{
+    if (!h || !d_x || !d_y) { set_error("spmv_bitmap_run: null argument"); return SPMV_ERR_INVALID; }
+    if (int rc = require_current(bitmap_device(*h), "spmv_bitmap_run")) return rc;
+    return bitmap_run(*h, d_x, d_y, (hipStream_t)stream);
+}
+
+int spmv_bitmap_run_host(const spmv_bitmap_t *h, const float *x_host, float *y_host, float *kernel_ms)
+{
+    if (!h || !x_host || !y_host) { set_error("spmv_bitmap_run_host: null argument"); return SPMV_ERR_INVALID; }
+    int M = 0, N = 0;
+    bitmap_info(*h, nullptr, &M, &N, nullptr, nullptr, nullptr);
+    DevBuf dx, dy;
+    EventPair ev;
+    SPMV_HIP_TRY(dx.alloc(sizeof(float) * (size_t)M));
+    SPMV_HIP_TRY(dy.alloc(sizeof(float) * (size_t)N));
+    SPMV_HIP_TRY(hipMemcpy(dx.p, x_host, sizeof(float) * (size_t)M, hipMemcpyHostToDevice));
+    SPMV_HIP_TRY(hipEventCreate(&ev.a));
+    SPMV_HIP_TRY(hipEventCreate(&ev.b));
+    int rc = bitmap_run(*h, (const float *)dx.p, (float *)dy.p, nullptr);   // warm
+    if (rc) return rc;
+    SPMV_HIP_TRY(hipDeviceSynchronize());
+    SPMV_HIP_TRY(hipEventRecord(ev.a, nullptr));
+    rc = bitmap_run(*h, (const float *)dx.p, (float *)dy.p, nullptr);
+    SPMV_HIP_TRY(hipEventRecord(ev.b, nullptr));
+    SPMV_HIP_TRY(hipEventSynchronize(ev.b));
+    if (rc) return rc;
+    float ms = 0.0f;
+    SPMV_HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+    if (kernel_ms) *kernel_ms = ms;
+    SPMV_HIP_TRY(hipMemcpy(y_host, dy.p, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost));
+    return SPMV_OK;
+}
+
+int spmv_bitmap_destroy(spmv_bitmap_t *h)
+{
+    bitmap_free(h);
+    return SPMV_OK;
+}
+
 int spmv_dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, void *stream)
 {
     if (M < 0 || N < 0 || ((int64_t)M * N > 0 && (!d_A || !d_x)) || (N > 0 && !d_y)) {

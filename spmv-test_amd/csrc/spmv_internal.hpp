@@ -102,7 +102,8 @@ struct PanelPlan {
 
 }  // namespace spmv
 
-struct spmv_tcsr;  // kernels_tcsr.hip
+struct spmv_tcsr;    // kernels_tcsr.hip
+struct spmv_bitmap;  // kernels_bitmap.hip
 
 // The opaque handle of include/spmv_hip.h.
 struct spmv_csr {
@@ -159,6 +160,14 @@ int tcsr_sizes(const spmv_tcsr &h, int64_t *n_blk_idx, int64_t *n_bitmaps, int64
 int tcsr_download(const spmv_tcsr &h, int32_t *blk_idx, uint32_t *bitmaps, float *vals);
 void tcsr_free(spmv_tcsr *h);
 void tcsr_dims(const spmv_tcsr &h, int *M, int *N);
+
+// kernels_bitmap.hip: the reference's WSP / AWSP / AWSPRef formats
+int bitmap_from_dense(int format, int M, int N, const float *d_A, hipStream_t s, spmv_bitmap_t **out);
+int bitmap_run(const spmv_bitmap &h, const float *d_x, float *d_y, hipStream_t s);
+void bitmap_info(const spmv_bitmap &h, int *format, int *M, int *N, int64_t *n_bitmaps, int64_t *n_vals, int32_t stats[4]);
+int bitmap_download(const spmv_bitmap &h, uint32_t *bitmaps, float *vals);
+int bitmap_device(const spmv_bitmap &h);
+void bitmap_free(spmv_bitmap *h);
 
 int synth_fill(uint64_t seed, int64_t row0, int64_t n_local, int64_t rows, int64_t cols, int64_t band,
                const int32_t *d_row_ptr, int32_t *d_col_idx, float *d_vals, hipStream_t s);

@@ -41,6 +41,20 @@ void run_tcsr(int M, int N, float *A_host, float *X_host, float *Y_host)
     SPMV_CHECK(spmv_tcsr_destroy(t));
 }
 
+// the reference's wsp / awsp / wsp_sm launchers multiply their own bitmap formats (wsp.cu:140-202, awsp.cu:319-388,
+// wsp_sm.cu:213-265 on the AWSPRef arrays); the same formats exist here for 32-aligned sizes, other sizes go
+// through the CSR variant named as the fallback
+void run_bitmap(int M, int N, float *A_host, float *X_host, float *Y_host, int format, int fallback_variant)
+{
+    if (M % 32 || N % 32) { run_csr(M, N, A_host, X_host, Y_host, fallback_variant); return; }
+    spmv_bitmap_t *b = nullptr;
+    SPMV_CHECK(spmv_bitmap_from_dense_host(format, M, N, A_host, nullptr, &b));
+    float kernel_ms = 0.0f;
+    std::cout << "[bitmap format " << format << ", rows=" << N << ", cols=" << M << "] ";
+    TIME_KERNEL(spmv_bitmap_run_host(b, X_host, Y_host, &kernel_ms));
+    SPMV_CHECK(spmv_bitmap_destroy(b));
+}
+
 [[noreturn]] void bad_version(const char *name, int version)
 {
     fprintf(stderr, "HIP error %s: unknown version %d\n", name, version);
@@ -55,14 +69,14 @@ void cublas_gemv_gpu(int M, int N, float *A, float *X, float *Y) { run_dense(M, 
 
 void csr_naive_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_csr(M, N, A_host, X_host, Y_host, SPMV_SCALAR); }
 void csr_tiling_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_tcsr(M, N, A_host, X_host, Y_host); }
-void wsp_sm_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_csr(M, N, A_host, X_host, Y_host, SPMV_TILED); }
+void wsp_sm_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_bitmap(M, N, A_host, X_host, Y_host, SPMV_FMT_AWSP_REF, SPMV_TILED); }
 void awsp_ref_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host) { run_csr(M, N, A_host, X_host, Y_host, SPMV_SCALAR); }
 
 void wsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version)
 {
     switch (version) {
-        case 0: run_csr(M, N, A_host, X_host, Y_host, SPMV_WAVE); break;
-        case 1: run_csr(M, N, A_host, X_host, Y_host, SPMV_WAVE_PIPE); break;
+        case 0: run_bitmap(M, N, A_host, X_host, Y_host, SPMV_FMT_WSP, SPMV_WAVE); break;   // the WSP format itself
+        case 1: run_csr(M, N, A_host, X_host, Y_host, SPMV_WAVE_PIPE); break;                // wavefront-per-64-rows on CSR
         default: bad_version("wsp_gemv_gpu", version);
     }
 }
@@ -82,7 +96,7 @@ void awsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, in
     // the adaptive slot adapts: version 2 (the reference's most developed kernel, awsp.cu:186-317) lets the library
     // choose between the LDS-tiled kernel and the panel sweep from the matrix itself (SPMV_AUTO)
     switch (version) {
-        case 0: run_csr(M, N, A_host, X_host, Y_host, SPMV_ADAPTIVE); break;
+        case 0: run_bitmap(M, N, A_host, X_host, Y_host, SPMV_FMT_AWSP, SPMV_ADAPTIVE); break;   // the AWSP format itself
         case 1: run_csr(M, N, A_host, X_host, Y_host, SPMV_TILED); break;
         case 2: run_csr(M, N, A_host, X_host, Y_host, SPMV_AUTO); break;
         default: bad_version("awsp_gemv_gpu", version);
