@@ -28,7 +28,7 @@ void naive_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host); 
 void csr_naive_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);   // SPMV_SCALAR
 void csr_tiling_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);  // tiled bitmap-CSR (spmv_tcsr_*)
 void wsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);   // 0 WSP bitmap format (SPMV_WAVE if not 32-aligned), 1 SPMV_WAVE_PIPE
-void asp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);   // 0,1 SPMV_VECTOR; 2 dense + x==0 skip
+void asp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);   // 0 SPMV_VECTOR; 1 SPMV_XSKIP; 2 dense + x==0 skip
 void awsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version);  // 0 AWSP bitmap format (SPMV_ADAPTIVE if not 32-aligned), 1 SPMV_TILED, 2 SPMV_AUTO
 void awsp_ref_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);    // SPMV_SCALAR (reference order)
 void wsp_sm_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);      // AWSPRef bitmap format (SPMV_TILED if not 32-aligned)

@@ -80,7 +80,14 @@ enum spmv_variant {
                         /* locality) and x is larger than one XCD's L2.  spmv_csr_plan_describe names   */
                         /* the choice.  Role: the reference's adaptive slot awsp_gemv_gpu               */
                         /* (src/kernels/awsp.cu:319-388), which the launcher of that name now runs.     */
-    SPMV_VARIANT_COUNT = 8
+    SPMV_XSKIP = 8,     /* activation sparsity on the CSR side: the plan re-orders the matrix into input-major */
+                        /* segments per block of 1024 outputs; a run skips, whole, the segments of the inputs    */
+                        /* whose x is zero (6 contiguous bytes per nonzero never read) and sums the rest in LDS. */
+                        /*   the `x_i != 0` skip of asp_kernel_v* (src/kernels/asp.cu:20-26), awsp_kernel_v1     */
+                        /*   (awsp.cu:127-134), awsp_ref_kernel (awsp_ref.cu:52).  For dense-ish matrices (the    */
+                        /*   reference's regime): the plan refuses when ceil(rows/1024) x cols exceeds 2^27, and  */
+                        /*   rows must be duplicate-free.  Its plan COPIES the values, like SPMV_PANEL.           */
+    SPMV_VARIANT_COUNT = 9
 };
 
 /* ---- runtime ---------------------------------------------------------- */

@@ -15,9 +15,12 @@ LAUNCHERS_PATH = PKG_DIR / "lib" / "libspmv_launchers.so"
 TESTER_PATH = PKG_DIR / "bin" / "sparse_sgemv"
 
 # enum spmv_variant
-SCALAR, WAVE, WAVE_PIPE, VECTOR, ADAPTIVE, TILED, PANEL, AUTO = range(8)
+SCALAR, WAVE, WAVE_PIPE, VECTOR, ADAPTIVE, TILED, PANEL, AUTO, XSKIP = range(9)
+# the variants that accept ANY CSR matrix ...
 VARIANTS = {"scalar": SCALAR, "wave": WAVE, "wave_pipe": WAVE_PIPE, "vector": VECTOR,
             "adaptive": ADAPTIVE, "tiled": TILED, "panel": PANEL, "auto": AUTO}
+# ... and with the one that is limited to dense-ish matrices (its plan refuses the others)
+ALL_VARIANTS = dict(VARIANTS, xskip=XSKIP)
 
 # enum spmv_status
 OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_VARIANT, ERR_NOT_PLANNED = 0, -1, -2, -3, -4, -5

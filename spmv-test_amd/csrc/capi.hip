@@ -108,6 +108,7 @@ const char *spmv_variant_name(int variant)
         case SPMV_TILED: return "tiled";
         case SPMV_PANEL: return "panel";
         case SPMV_AUTO: return "auto";
+        case SPMV_XSKIP: return "xskip";
         default: return "unknown";
     }
 }
@@ -322,6 +323,7 @@ int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream)
         case SPMV_ADAPTIVE: return plan_adaptive(*h, false, s);
         case SPMV_TILED: return plan_adaptive(*h, true, s);
         case SPMV_PANEL: return plan_panel(*h, s);
+        case SPMV_XSKIP: return plan_xskip(*h, s);
         default:
             set_error("spmv_csr_plan: unknown variant %d", variant);
             return SPMV_ERR_VARIANT;
@@ -352,6 +354,7 @@ int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void 
         case SPMV_ADAPTIVE: return launch_adaptive(*h, d_x, d_y, false, s);
         case SPMV_TILED: return launch_adaptive(*h, d_x, d_y, true, s);
         case SPMV_PANEL: return launch_panel(*h, d_x, d_y, s);
+        case SPMV_XSKIP: return launch_xskip(*h, d_x, d_y, s);
         default:
             set_error("spmv_csr_run: unknown variant %d", variant);
             return SPMV_ERR_VARIANT;
@@ -377,6 +380,10 @@ int spmv_csr_plan_get(const spmv_csr_t *h, int variant, int32_t params[8])
             params[1] = p.block; params[2] = p.maxpass; params[3] = p.col16_wanted ? 1 : 0;
             return SPMV_OK;
         }
+        case SPMV_XSKIP:
+            if (!h->plan_xskip.ready) { set_error("spmv_csr_plan_get: xskip is not planned"); return SPMV_ERR_NOT_PLANNED; }
+            params[1] = h->plan_xskip.slabs;
+            return SPMV_OK;
         case SPMV_PANEL:
             if (!h->plan_panel.ready) { set_error("spmv_csr_plan_get: panel is not planned"); return SPMV_ERR_NOT_PLANNED; }
             params[4] = h->plan_panel.pw_bits; params[5] = h->plan_panel.waves_per_launch;
@@ -414,6 +421,7 @@ int spmv_csr_plan_set(spmv_csr_t *h, int variant, const int32_t params[8], void 
         case SPMV_ADAPTIVE: rc = plan_adaptive_with(*h, params[1], s); break;
         case SPMV_TILED: rc = plan_tiled_with(*h, params[1], params[2], params[3] != 0, s); break;
         case SPMV_PANEL: rc = plan_panel_with(*h, params[4], params[5], s); break;
+        case SPMV_XSKIP: rc = plan_xskip(*h, s); break;
         default: set_error("spmv_csr_plan_set: unknown variant %d", target); return SPMV_ERR_VARIANT;
     }
     if (rc == SPMV_OK && variant == SPMV_AUTO) h->auto_variant = target;
@@ -440,6 +448,9 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
                    (int64_t)h->plan_tiled.n16 * 2 * h->plan_tiled.block * kNnzPerThread +
                    (int64_t)h->plan_tiled.nsorted * 4 * h->plan_tiled.block * kNnzPerThread +
                    (int64_t)h->plan_tiled.nblk_chunks * 256 * 4;   // block lists: up to 256 ids per chunk that has one
+        case SPMV_XSKIP:     // segment list + slab partials; erow16/evals (6 B per nonzero) REPLACE col_idx/vals (8 B)
+            return (int64_t)h->plan_xskip.nseg * 8 + ((int64_t)h->plan_xskip.nblocks + 1) * 4 +
+                   (h->plan_xskip.slabs > 1 ? (int64_t)h->plan_xskip.nblocks * h->plan_xskip.slabs * 1024 * 8 : 0);
         case SPMV_PANEL:     // tile_ptr; packed/pvals REPLACE col_idx/vals byte for byte
             return (int64_t)h->plan_panel.nblocks * (h->plan_panel.npanels + 1) * 4 + ((int64_t)h->plan_panel.nblocks + 1) * 4;
         default: return 0;
@@ -461,6 +472,9 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
         snprintf(buf, (size_t)n, "panel_columns=%d panels=%d row_blocks=%d waves_per_launch=%d launches=%d",
                  1 << h->plan_panel.pw_bits, h->plan_panel.npanels, h->plan_panel.nblocks,
                  h->plan_panel.waves_per_launch, panel_launches(h->plan_panel));
+    else if (variant == SPMV_XSKIP && h->plan_xskip.ready)
+        snprintf(buf, (size_t)n, "output_blocks=%d segments=%d slabs_per_block=%d", h->plan_xskip.nblocks, h->plan_xskip.nseg,
+                 h->plan_xskip.slabs);
     else if (!p) snprintf(buf, (size_t)n, "no plan");
     else if (!p->block) snprintf(buf, (size_t)n, "not planned");
     else

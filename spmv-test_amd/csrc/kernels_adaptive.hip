@@ -1486,6 +1486,7 @@ void destroy_plans(spmv_csr &h)
     free_plan(h.plan_adaptive);
     free_plan(h.plan_tiled);
     destroy_panel(h.plan_panel);
+    destroy_xskip(h.plan_xskip);
 }
 
 static int resident_workgroups(int device, int block, int waves_simd)

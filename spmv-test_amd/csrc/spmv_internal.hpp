@@ -100,6 +100,18 @@ struct PanelPlan {
     int32_t *d_brow = nullptr;     // [nblocks + 1] first row of every block
 };
 
+// SPMV_XSKIP (kernels_xskip.hip): the matrix in input-major segments per block of 1024 outputs
+struct XskipPlan {
+    bool ready = false;
+    int nblocks = 0, nseg = 0, slabs = 0;
+    int32_t *d_block_seg = nullptr;   // [nblocks+1] first segment of every output block
+    int32_t *d_seg_input = nullptr;   // [nseg+1] input (column) of a segment
+    int32_t *d_seg_ptr = nullptr;     // [nseg+1] first entry of a segment
+    uint16_t *d_erow = nullptr;       // [nnz] output - 1024 * block
+    float *d_evals = nullptr;         // [nnz] values in segment order (a COPY: re-plan after changing vals)
+    float *d_part = nullptr;          // [nblocks * slabs * 1024] slab partials (slabs > 1)
+};
+
 }  // namespace spmv
 
 struct spmv_tcsr;    // kernels_tcsr.hip
@@ -119,6 +131,7 @@ struct spmv_csr {
     spmv::ChunkPlan plan_adaptive; // SPMV_ADAPTIVE: 256-thread workgroups
     spmv::ChunkPlan plan_tiled;    // SPMV_TILED: workgroup size chosen from the column windows
     spmv::PanelPlan plan_panel;    // SPMV_PANEL
+    spmv::XskipPlan plan_xskip;    // SPMV_XSKIP
     int auto_variant = -1;         // SPMV_AUTO: the variant its plan chose (-1 = not planned)
 };
 
@@ -131,6 +144,9 @@ int launch_vector(const spmv_csr &h, const float *x, float *y, hipStream_t s);
 int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s);
 int launch_panel(const spmv_csr &h, const float *x, float *y, hipStream_t s);
 
+int plan_xskip(spmv_csr &h, hipStream_t s);
+int launch_xskip(const spmv_csr &h, const float *x, float *y, hipStream_t s);
+void destroy_xskip(XskipPlan &p);
 int plan_panel(spmv_csr &h, hipStream_t s);
 void destroy_panel(PanelPlan &p);
 int panel_launches(const PanelPlan &p);

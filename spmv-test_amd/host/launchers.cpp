@@ -81,13 +81,14 @@ void wsp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int
     }
 }
 
-// the reference's ASP kernels keep A dense and skip the rows whose x is zero (asp.cu:20-26): versions 0/1
-// run the lanes-per-row CSR kernel, version 2 -- the one the tester registers (tester.cpp:58) -- the dense
-// split-M kernel with that activation-sparsity skip
+// the reference's ASP kernels keep A dense and skip the rows whose x is zero (asp.cu:20-26): version 0 runs the
+// lanes-per-row CSR kernel, version 1 the input-major sweep that skips the segments of zero inputs (SPMV_XSKIP), version
+// 2 -- the one the tester registers (tester.cpp:58) -- the dense split-M kernel with that activation-sparsity skip
 void asp_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host, int version)
 {
     if (version < 0 || version > 2) bad_version("asp_gemv_gpu", version);
     if (version == 2) run_dense(M, N, A_host, X_host, Y_host, 3);
+    else if (version == 1) run_csr(M, N, A_host, X_host, Y_host, SPMV_XSKIP);   // the same skip on the compressed matrix
     else run_csr(M, N, A_host, X_host, Y_host, SPMV_VECTOR);
 }
 

@@ -13,14 +13,19 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-VARIANT_NAMES = ["scalar", "wave", "wave_pipe", "vector", "adaptive", "tiled", "panel", "auto"]
+VARIANT_NAMES = ["scalar", "wave", "wave_pipe", "vector", "adaptive", "tiled", "panel", "auto", "xskip"]
 
 
 def _check_all_variants(pkg, oracle, prob, what):
     y_seq = oracle.spmv(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
     y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
     for name in VARIANT_NAMES:
-        y = prob.run(pkg.capi.VARIANTS[name])
+        try:
+            y = prob.run(pkg.capi.ALL_VARIANTS[name])
+        except pkg.capi.SpmvError as e:
+            if name == "xskip" and "dense-ish" in str(e):      # large sparse matrix: that variant says it is not for it
+                continue
+            raise
         assert not np.isnan(y).any() or np.isnan(y_seq).any(), f"{what}/{name}: rows left unwritten"
         if name == "scalar":
             assert np.array_equal(y.view(np.uint32), y_seq.view(np.uint32)), f"{what}: scalar not bit-identical"
@@ -263,7 +268,8 @@ def test_launchers_from_python_match_oracle(pkg, oracle, gpu, M, N, zero, seed):
     y64, mag = oracle.spmv_f64(rp, ci, va, x)
     vp, ci_ = ctypes.c_void_p, ctypes.c_int
     calls = [("_Z15cublas_gemv_gpuiiPfS_S_", None), ("_Z12wsp_gemv_gpuiiPfS_S_i", 0), ("_Z12wsp_gemv_gpuiiPfS_S_i", 1),
-             ("_Z12asp_gemv_gpuiiPfS_S_i", 2), ("_Z13awsp_gemv_gpuiiPfS_S_i", 0), ("_Z13awsp_gemv_gpuiiPfS_S_i", 1),
+             ("_Z12asp_gemv_gpuiiPfS_S_i", 2), ("_Z12asp_gemv_gpuiiPfS_S_i", 0), ("_Z12asp_gemv_gpuiiPfS_S_i", 1),
+             ("_Z13awsp_gemv_gpuiiPfS_S_i", 0), ("_Z13awsp_gemv_gpuiiPfS_S_i", 1),
              ("_Z13awsp_gemv_gpuiiPfS_S_i", 2), ("_Z17awsp_ref_gemv_gpuiiPfS_S_", None),
              ("_Z18csr_naive_gemv_gpuiiPfS_S_", None), ("_Z19csr_tiling_gemv_gpuiiPfS_S_", None),
              ("_Z14naive_gemv_gpuiiPfS_S_", None), ("_Z15tiling_gemv_gpuiiPfS_S_", None),

@@ -48,8 +48,13 @@ def test_random_structures_all_variants(pkg, oracle, gpu, runs, cols, seed):
     prob = DeviceProblem(pkg, gpu, len(lengths), cols, rp, ci, va, x)
     y_seq = oracle.spmv(rp, ci, va, x)
     y64, mag = oracle.spmv_f64(rp, ci, va, x)
-    for name, v in pkg.capi.VARIANTS.items():
-        y = prob.run(v)
+    for name, v in pkg.capi.ALL_VARIANTS.items():      # xskip included: rows here are sorted and duplicate-free
+        try:
+            y = prob.run(v)
+        except pkg.capi.SpmvError as e:
+            if name == "xskip" and "dense-ish" in str(e):
+                continue
+            raise
         assert not np.isnan(y).any(), f"{name}: rows left unwritten"
         if name == "scalar":
             assert np.array_equal(y.view(np.uint32), y_seq.view(np.uint32))

@@ -48,7 +48,7 @@ def test_launcher_library_has_the_reference_symbols(pkg):
 
 def test_variant_names(pkg):
     lib = pkg.capi.lib()
-    for name, v in pkg.capi.VARIANTS.items():
+    for name, v in pkg.capi.ALL_VARIANTS.items():
         assert lib.spmv_variant_name(v).decode() == name
     assert lib.spmv_variant_name(99).decode() == "unknown"
 

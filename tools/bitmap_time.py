@@ -32,7 +32,8 @@ def main():
             best = ms if best is None or ms < best else best
         return best
 
-    for n, zero, xzero in ((4096, 0.5, 0.5), (4096, 0.5, 0.0), (4096, 0.9, 0.5), (16384, 0.5, 0.5), (16384, 0.9, 0.0)):
+    for n, zero, xzero in ((4096, 0.5, 0.5), (4096, 0.5, 0.0), (4096, 0.9, 0.5), (16384, 0.5, 0.5), (16384, 0.5, 0.9),
+                           (16384, 0.9, 0.0)):
         rng = np.random.Generator(np.random.PCG64(n))
         dA = (torch.rand(n, n, device=dev) * 2 - 1) * (torch.rand(n, n, device=dev) >= zero)
         dx = (torch.rand(n, device=dev) * 2 - 1) * (torch.rand(n, device=dev) >= xzero)
@@ -41,8 +42,8 @@ def main():
         csr = capi.CsrMatrix.from_dense_device(dA)
         out["nnz"] = csr.nnz
         out["csr_bytes"] = W.algorithmic_bytes(n, n, csr.nnz)
-        for vn in ("wave", "wave_pipe", "adaptive", "tiled"):
-            v = capi.VARIANTS[vn]
+        for vn in ("wave", "wave_pipe", "adaptive", "tiled", "xskip"):
+            v = capi.ALL_VARIANTS[vn]
             csr.plan(v)
             out[f"csr_{vn}_ms"] = round(timed(lambda: csr.run(v, dx, dy)), 5)
         ref = dy.clone()
