@@ -264,9 +264,16 @@ def main():
                     traffic_source = f"profiles/{ent.get('profile')} was taken with another plan ({ent.get('plan')}): not replayed"
             except Exception:
                 traffic = None
-        dom_kernel = ("k_panel" if resolved == "panel" else
-                      "k_tiled16" if resolved == "tiled" and " col16_chunks=0 " not in plan_now else
-                      "k_adaptive" if resolved in ("adaptive", "tiled") else f"k_{resolved}")
+        def _n(key):
+            return int(plan_now.split(key + "=")[1].split()[0]) if key + "=" in plan_now else 0
+        if resolved == "panel":
+            dom_kernel = "k_panel"
+        elif resolved == "tiled" and (_n("col16_chunks") or _n("sorted_chunks")):
+            # one launch: all chunks 16-bit -> k_tiled16, all sorted -> k_sorted, otherwise the three bodies in k_tiled_mixed
+            dom_kernel = ("k_tiled16" if _n("col16_chunks") == _n("chunks") else
+                          "k_sorted" if _n("sorted_chunks") == _n("chunks") else "k_tiled_mixed")
+        else:
+            dom_kernel = "k_adaptive" if resolved in ("adaptive", "tiled") else f"k_{resolved}"
         out = {
             "metric": "fp32 CSR SpMV throughput in CSR-algorithmic bytes per second (8/nnz + row_ptr + x + y over time; "
                       "roofline.frac_hbm_counters is the FETCH_SIZE/WRITE_SIZE-based figure)",

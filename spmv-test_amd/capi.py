@@ -13,6 +13,8 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "lib" / "libspmv_hip.so"
 LAUNCHERS_PATH = PKG_DIR / "lib" / "libspmv_launchers.so"
 TESTER_PATH = PKG_DIR / "bin" / "sparse_sgemv"
+DIST_LIB_PATH = PKG_DIR / "lib" / "libspmv_dist.so"            # include/spmv_dist.h (RCCL; not loaded by this module)
+DIST_SELFTEST_PATH = PKG_DIR / "bin" / "spmv_dist_selftest"
 
 # enum spmv_variant
 SCALAR, WAVE, WAVE_PIPE, VECTOR, ADAPTIVE, TILED, PANEL, AUTO, XSKIP = range(9)

@@ -286,8 +286,8 @@ int spmv_csr_destroy(spmv_csr_t *h)
 
 // SPMV_AUTO: plan TILED (cheap: a few passes over col_idx, no trial launches) and look at what it could stage.
 // A plan that stages less than half of the chunks gathers most of x through L2/fabric -- one request per nonzero --
-// and when x is larger than one XCD's 4 MiB L2 that is where the panel sweep is 3-4x faster;
-// below that size x sits in every L2 anyway and the row-major kernel keeps its lead.
+// and when x fills one XCD's 4 MiB L2 or more that is where the panel sweep is faster (1.2x at config 2's 4 MiB, 3-4x at
+// 64 MiB: DESIGN.md section 4); below that size x sits in every L2 anyway and the row-major kernel keeps its lead.
 static int plan_auto(spmv_csr &h, hipStream_t s)
 {
     if (h.auto_variant >= 0) return SPMV_OK;
@@ -296,7 +296,7 @@ static int plan_auto(spmv_csr &h, hipStream_t s)
     const ChunkPlan &p = h.plan_tiled;
     const bool little_staged = p.nchunks > 0 && 2 * ((int64_t)p.staged_full + p.nsorted) < p.nchunks &&
                                2 * (int64_t)p.nblk_chunks < p.nchunks;
-    const bool x_beyond_l2 = h.cols * (int64_t)sizeof(float) > (4ll << 20);
+    const bool x_beyond_l2 = h.cols * (int64_t)sizeof(float) >= (4ll << 20);   // an L2 also holds the stream passing through
     if (little_staged && x_beyond_l2) {
         rc = plan_panel(h, s);
         if (rc == SPMV_OK) {

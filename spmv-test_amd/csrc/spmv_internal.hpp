@@ -75,6 +75,7 @@ struct ChunkPlan {
     int nsorted = 0;                   // chunks run by the sorted body
     int nsorted_marked = 0;            // chunks the window pass marked (a few may still switch to a block list)
     int sorted_from = 0;               // -1: sorted where the modelled cost is lower; 0: never; n: from n passes on
+    int long_piece_chunks = 0;         // chunks of three passes or more that hold a piece of a long row (> 512 nonzeros)
     double model_cost = 0.0;           // modelled time per nonzero of this plan (PlanCost units; compares block sizes)
     int32_t *d_blk = nullptr;      // [64 * nchunks] ids of the staged 1024-column blocks of the chunks that use a list
     int nblk_chunks = 0;           // how many chunks do

@@ -1,0 +1,192 @@
+// dist_selftest.cpp -- bin/spmv_dist_selftest: the sharded SpMV of include/spmv_dist.h, all ranks in ONE process
+// (spmv_dist_init_all = ncclCommInitAll, the first process model of SURVEY.md section 8e), checked against the whole
+// matrix multiplied by a single handle.  Also the worked example of INTEGRATION.md for a C++ caller.
+//
+//   spmv_dist_selftest [--ranks N] [--rows-per-rank R] [--band B] [--unequal] [--variant tiled|adaptive|scalar] [--steps K]
+// N defaults to the number of visible GPUs.  Matrix: (N*R)^2, 16 nonzeros per row (config 2's law), generated on
+// the devices by spmv_synth_fill; with --unequal the blocks hold R-17, R+17, ... rows (the all-gather-v path).
+// Prints one JSON line; exit code 0 iff every rank's y is bit-identical to the single-handle result.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "spmv_dist.h"
+
+#define OK_HIP(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess) { fprintf(stderr, "HIP error %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e__)); exit(EXIT_FAILURE); } \
+    } while (0)
+#define OK_SPMV(call)                                                                                 \
+    do {                                                                                              \
+        int rc__ = (call);                                                                            \
+        if (rc__ != SPMV_OK) { fprintf(stderr, "error %s:%d: %s | %s\n", __FILE__, __LINE__, spmv_last_error(), spmv_dist_last_error()); exit(EXIT_FAILURE); } \
+    } while (0)
+
+struct Rank {
+    int device = 0;
+    int64_t r0 = 0, r1 = 0;
+    int32_t *d_rp = nullptr, *d_ci = nullptr;
+    float *d_va = nullptr, *d_x = nullptr, *d_y = nullptr;
+    spmv_csr_t *A = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+int main(int argc, char **argv)
+{
+    int ndev = spmv_device_count();
+    int64_t per = 1 << 18, band = 4096;
+    bool unequal = false;
+    int variant = SPMV_TILED, steps = 20;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", a.c_str()); exit(2); } return argv[++i]; };
+        if (a == "--ranks") ndev = atoi(next());
+        else if (a == "--rows-per-rank") per = atoll(next());
+        else if (a == "--band") band = atoll(next());
+        else if (a == "--steps") steps = atoi(next());
+        else if (a == "--unequal") unequal = true;
+        else if (a == "--variant") {
+            std::string v = next();
+            variant = v == "adaptive" ? SPMV_ADAPTIVE : v == "scalar" ? SPMV_SCALAR : v == "auto" ? SPMV_AUTO : SPMV_TILED;
+        } else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    if (ndev < 1 || ndev > spmv_device_count()) { fprintf(stderr, "HIP error: %d ranks asked, %d devices visible\n", ndev, spmv_device_count()); return EXIT_FAILURE; }
+    const uint64_t seed = 20251031;
+    const int64_t rows = per * ndev, cols = rows;
+    const int nnz_row = 16;
+
+    std::vector<int64_t> bounds(ndev + 1, 0);
+    for (int r = 0; r < ndev; ++r) {
+        int64_t n = per;
+        if (unequal && ndev > 1) n += (r % 2 ? 17 : -17) * (r + 1 < ndev || ndev % 2 == 0 ? 1 : 0);
+        bounds[r + 1] = bounds[r] + n;
+    }
+    bounds[ndev] = rows;
+
+    std::vector<spmv_dist_t *> dist(ndev, nullptr);
+    OK_SPMV(spmv_dist_init_all(ndev, nullptr, dist.data()));
+    std::vector<Rank> rk(ndev);
+    for (int r = 0; r < ndev; ++r) {
+        Rank &R = rk[r];
+        OK_SPMV(spmv_dist_rank(dist[r], nullptr, nullptr, &R.device));
+        OK_HIP(hipSetDevice(R.device));
+        OK_HIP(hipStreamCreate(&R.stream));
+        OK_SPMV(spmv_dist_set_partition(dist[r], bounds.data(), cols));
+        R.r0 = bounds[r]; R.r1 = bounds[r + 1];
+        const int64_t n = R.r1 - R.r0, nnz = n * nnz_row;
+        std::vector<int32_t> rp(n + 1);
+        for (int64_t i = 0; i <= n; ++i) rp[i] = (int32_t)(i * nnz_row);
+        OK_HIP(hipMalloc((void **)&R.d_rp, sizeof(int32_t) * (n + 1)));
+        OK_HIP(hipMalloc((void **)&R.d_ci, sizeof(int32_t) * (nnz ? nnz : 1)));
+        OK_HIP(hipMalloc((void **)&R.d_va, sizeof(float) * (nnz ? nnz : 1)));
+        OK_HIP(hipMalloc((void **)&R.d_x, sizeof(float) * cols));
+        OK_HIP(hipMalloc((void **)&R.d_y, sizeof(float) * rows));
+        OK_HIP(hipMemcpy(R.d_rp, rp.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+        OK_HIP(hipMemset(R.d_y, 0xff, sizeof(float) * rows));                       // NaNs: every row must be overwritten
+        OK_SPMV(spmv_synth_fill(seed, R.r0, n, rows, cols, band, R.d_rp, R.d_ci, R.d_va, R.stream));
+        OK_SPMV(spmv_csr_create_device(n, cols, nnz, R.d_rp, R.d_ci, R.d_va, &R.A));
+        if (r == 0) OK_SPMV(spmv_synth_x(seed, 0, cols, R.d_x, R.stream));
+        OK_HIP(hipStreamSynchronize(R.stream));
+    }
+    // the dense vector, broadcast once
+    OK_SPMV(spmv_dist_group_start());
+    for (int r = 0; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_SPMV(spmv_dist_broadcast_x(dist[r], rk[r].d_x, 0, rk[r].stream)); }
+    OK_SPMV(spmv_dist_group_end());
+    // every block planned like block 0 (all ranks live in this process: the numbers travel by hand)
+    int32_t params[8];
+    OK_HIP(hipSetDevice(rk[0].device));
+    OK_SPMV(spmv_csr_plan(rk[0].A, variant, rk[0].stream));
+    OK_SPMV(spmv_csr_plan_get(rk[0].A, variant, params));
+    for (int r = 1; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_SPMV(spmv_csr_plan_set(rk[r].A, variant, params, rk[r].stream)); }
+
+    auto step = [&]() {
+        OK_SPMV(spmv_dist_group_start());
+        for (int r = 0; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            OK_SPMV(spmv_dist_spmv(dist[r], rk[r].A, variant, rk[r].d_x, rk[r].d_y, rk[r].stream));
+        }
+        OK_SPMV(spmv_dist_group_end());
+    };
+    auto sync_all = [&]() { for (int r = 0; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_HIP(hipStreamSynchronize(rk[r].stream)); } };
+    step();
+    sync_all();
+
+    // the whole matrix through ONE handle on device 0, planned alike
+    OK_HIP(hipSetDevice(rk[0].device));
+    const int64_t nnz_all = rows * nnz_row;
+    std::vector<int32_t> rp_all(rows + 1);
+    for (int64_t i = 0; i <= rows; ++i) rp_all[i] = (int32_t)(i * nnz_row);
+    int32_t *d_rp, *d_ci;
+    float *d_va, *d_yref;
+    OK_HIP(hipMalloc((void **)&d_rp, sizeof(int32_t) * (rows + 1)));
+    OK_HIP(hipMalloc((void **)&d_ci, sizeof(int32_t) * nnz_all));
+    OK_HIP(hipMalloc((void **)&d_va, sizeof(float) * nnz_all));
+    OK_HIP(hipMalloc((void **)&d_yref, sizeof(float) * rows));
+    OK_HIP(hipMemcpy(d_rp, rp_all.data(), sizeof(int32_t) * (rows + 1), hipMemcpyHostToDevice));
+    OK_SPMV(spmv_synth_fill(seed, 0, rows, rows, cols, band, d_rp, d_ci, d_va, rk[0].stream));
+    spmv_csr_t *whole = nullptr;
+    OK_SPMV(spmv_csr_create_device(rows, cols, nnz_all, d_rp, d_ci, d_va, &whole));
+    OK_SPMV(spmv_csr_plan_set(whole, variant, params, rk[0].stream));
+    OK_SPMV(spmv_csr_run(whole, variant, rk[0].d_x, d_yref, rk[0].stream));
+    OK_HIP(hipStreamSynchronize(rk[0].stream));
+    std::vector<float> yref(rows), y(rows);
+    OK_HIP(hipMemcpy(yref.data(), d_yref, sizeof(float) * rows, hipMemcpyDeviceToHost));
+    int64_t differing = 0;
+    for (int r = 0; r < ndev; ++r) {
+        OK_HIP(hipSetDevice(rk[r].device));
+        OK_HIP(hipMemcpy(y.data(), rk[r].d_y, sizeof(float) * rows, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < rows; ++i) differing += std::memcmp(&y[i], &yref[i], sizeof(float)) != 0;
+    }
+
+    // timing: K steps (multiply + exchange), multiply alone, exchange alone -- events on rank 0's stream
+    hipEvent_t e0, e1;
+    OK_HIP(hipSetDevice(rk[0].device));
+    OK_HIP(hipEventCreate(&e0));
+    OK_HIP(hipEventCreate(&e1));
+    auto timed = [&](auto &&body) {
+        sync_all();
+        OK_HIP(hipSetDevice(rk[0].device));
+        OK_HIP(hipEventRecord(e0, rk[0].stream));
+        for (int k = 0; k < steps; ++k) body();
+        OK_HIP(hipSetDevice(rk[0].device));
+        OK_HIP(hipEventRecord(e1, rk[0].stream));
+        sync_all();
+        float ms = 0;
+        OK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return ms / steps;
+    };
+    const float step_ms = timed(step);
+    const float mult_ms = timed([&]() {
+        for (int r = 0; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            OK_SPMV(spmv_csr_run(rk[r].A, variant, rk[r].d_x, rk[r].d_y + rk[r].r0, rk[r].stream));
+        }
+    });
+    const float xchg_ms = timed([&]() {
+        OK_SPMV(spmv_dist_group_start());
+        for (int r = 0; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_SPMV(spmv_dist_allgather_y(dist[r], rk[r].d_y, rk[r].stream)); }
+        OK_SPMV(spmv_dist_group_end());
+    });
+    char plan[256];
+    OK_HIP(hipSetDevice(rk[0].device));
+    OK_SPMV(spmv_csr_plan_describe(rk[0].A, variant, plan, sizeof plan));
+    const double bytes = 8.0 * nnz_all + 4.0 * (rows + ndev) + 4.0 * rows + 4.0 * cols * ndev;
+    printf("{\"world\": %d, \"process_model\": \"one process, ncclCommInitAll\", \"rows\": %lld, \"nnz\": %lld, \"band\": %lld, "
+           "\"unequal_blocks\": %s, \"variant\": \"%s\", \"rows_differing_from_single_handle\": %lld, \"step_ms\": %.5f, "
+           "\"multiply_only_ms\": %.5f, \"exchange_only_ms\": %.5f, \"aggregate_GBs\": %.1f, \"plan\": \"%s\"}\n",
+           ndev, (long long)rows, (long long)nnz_all, (long long)band, unequal ? "true" : "false", spmv_variant_name(variant),
+           (long long)differing, step_ms, mult_ms, xchg_ms, bytes / (step_ms * 1e-3) / 1e9, plan);
+    for (int r = 0; r < ndev; ++r) {
+        OK_HIP(hipSetDevice(rk[r].device));
+        (void)spmv_csr_destroy(rk[r].A);
+        (void)spmv_dist_destroy(dist[r]);
+    }
+    (void)spmv_csr_destroy(whole);
+    return differing == 0 ? 0 : 1;
+}

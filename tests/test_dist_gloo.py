@@ -57,19 +57,21 @@ def _worker(rank, world, port, balanced, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("balanced", [False, True])
-def test_two_rank_row_block_exchange(built, balanced):
+@pytest.mark.parametrize("world,balanced", [(2, False), (2, True), (4, True)], ids=["world2-equal", "world2-by-nnz", "world4-by-nnz"])
+def test_row_block_exchange(built, world, balanced):
+    """world 2 and world 4 (VERDICT next-7d: four ranks with UNEQUAL blocks -- the nnz-balanced cut of a power-law
+    matrix -- through the padded-slot all-gather), bit-exact against the whole problem on one rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, balanced, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, balanced, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=180)
+        p.join(timeout=240)
         assert p.exitcode == 0
-    res = sorted(q.get(timeout=10) for _ in range(2))
-    assert [r[1] for r in res] == [True, True]
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert [r[1] for r in res] == [True] * world
     assert all(r[2] == (not balanced) for r in res)      # equal rows -> in-place gather path
 
 
@@ -101,6 +103,8 @@ def _worker_pipe(rank, world, port, S, q):
         sh.broadcast_x(0)
         sh.step()
         y = sh.finish().numpy().copy()
+        sh.exchange_only()                    # the all-gathers alone (bench.py's exchange_only_ms) leave y unchanged
+        assert np.array_equal(sh.finish().numpy(), y)
         rp_all = W.row_ptr(w)
         ci_all, va_all = orc.synth_fill(w.seed, 0, w.rows, w.rows, w.cols, w.band, rp_all)
         y_ref = orc.spmv(rp_all, ci_all, va_all, orc.synth_x(w.seed, 0, w.cols))

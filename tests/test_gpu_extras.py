@@ -238,3 +238,19 @@ def test_plan_uses_16bit_columns_only_where_the_span_is_staged(pkg, oracle, gpu)
     pu = synth_problem(pkg, oracle, gpu, wu)
     pu.run(pkg.capi.TILED)
     assert "col16_chunks=0 " in pu.A.plan_describe(pkg.capi.TILED)
+
+
+def test_dist_selftest_world_of_one_gpu(pkg, gpu):
+    """include/spmv_dist.h end to end from C++ (bin/spmv_dist_selftest): RCCL communicator over the visible GPUs (one on
+    this box: the collectives degenerate, the partition / plan hand-over / step path does not), every rank's y
+    bit-identical to the whole matrix through a single handle.  On an 8-GPU node the same binary runs 8 ranks."""
+    import json
+    import subprocess
+    import torch
+    n = torch.cuda.device_count()
+    for extra in ([], ["--unequal", "--variant", "adaptive"]):
+        p = subprocess.run([str(pkg.capi.DIST_SELFTEST_PATH), "--ranks", str(n), "--rows-per-rank", str(1 << 18)] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+        out = json.loads(p.stdout.strip().splitlines()[-1])
+        assert out["world"] == n and out["rows_differing_from_single_handle"] == 0 and out["step_ms"] > 0

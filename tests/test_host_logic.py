@@ -10,6 +10,11 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def _no_gpu_early():
+    import torch
+    return not torch.cuda.is_available()
+
+
 # ---- C ABI ---------------------------------------------------------------------------------
 def _declared_symbols():
     text = (ROOT / "include" / "spmv_hip.h").read_text()
@@ -31,6 +36,23 @@ def test_library_exports_nothing_else(pkg):
                          check=True).stdout
     syms = [l.split()[-1] for l in out.splitlines() if " T " in l]
     assert syms and all(s.startswith("spmv_") for s in syms), syms
+
+
+def test_dist_library_exports_every_declared_symbol(pkg):
+    """include/spmv_dist.h (the row-block exchange over RCCL for a C++ caller) vs libspmv_dist.so."""
+    text = (ROOT / "include" / "spmv_dist.h").read_text()
+    declared = sorted(set(re.findall(r"SPMV_API[^;(]*?\b(spmv_dist_\w+)\s*\(", text)))
+    assert len(declared) >= 12
+    out = subprocess.run(["nm", "-D", "--defined-only", str(pkg.capi.DIST_LIB_PATH)], capture_output=True, text=True,
+                         check=True).stdout
+    syms = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert syms == declared
+
+
+@pytest.mark.skipif(not _no_gpu_early(), reason="only meaningful on a box without a GPU")
+def test_dist_selftest_exits_nonzero_without_a_device(pkg):
+    p = subprocess.run([str(pkg.capi.DIST_SELFTEST_PATH)], capture_output=True, text=True)
+    assert p.returncode != 0 and "HIP error" in p.stderr
 
 
 def test_launcher_library_has_the_reference_symbols(pkg):
