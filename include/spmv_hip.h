@@ -139,8 +139,9 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
  * A plan snapshots the sparsity PATTERN (row_ptr, col_idx): with borrowed
  * arrays (spmv_csr_create_device) the pattern must not change afterwards;
  * vals are read live on every run and may be updated freely -- except by
- * SPMV_PANEL, whose plan re-orders the nonzeros and keeps its own copy of the
- * values (plan again after changing them; its layout also replaces col_idx and
+ * SPMV_PANEL and SPMV_XSKIP, whose plans re-order the nonzeros and keep their own copy
+ * of the values (after changing them re-plan with spmv_csr_plan_set, which always
+ * rebuilds; spmv_csr_plan is idempotent; the panel layout also replaces col_idx and
  * vals byte for byte in what a run reads, and is limited to 2^29 columns).
  * spmv_csr_run: enqueue y = A x on `stream` (a hipStream_t, NULL = default).
  * Asynchronous; d_x has cols floats, d_y has rows floats and is fully
@@ -153,7 +154,8 @@ SPMV_API int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d
  *   params[0] variant actually planned (SPMV_AUTO resolves to SPMV_TILED or SPMV_PANEL)
  *   params[1] threads per workgroup (ADAPTIVE/TILED: 256 | 512 | 1024; a chunk is 16x that many nonzeros)
  *   params[2] staging-pass budget (TILED)        params[3] 1 = keep the 16-bit column copy where it pays (TILED)
- *   params[4] log2(columns per panel) (PANEL)    params[5] wavefronts per launch (PANEL)    params[6..7] 0
+ *   params[4] log2(columns per panel) (PANEL)    params[5] wavefronts per launch (PANEL)
+ *   params[6] PANEL: 1 = panels of x gathered through L2, 2 = staged in LDS (0 on input: the library's rule)    params[7] 0
  * spmv_csr_plan (the default) derives them from the matrix alone -- no timing -- so two handles of one matrix
  * already agree; handles of DIFFERENT row blocks of one matrix may not, and with SPMV_AUTOTUNE=1 nothing is
  * guaranteed.  spmv_csr_plan_set plans with exactly these numbers (replacing any existing plan of that variant),

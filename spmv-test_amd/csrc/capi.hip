@@ -387,6 +387,7 @@ int spmv_csr_plan_get(const spmv_csr_t *h, int variant, int32_t params[8])
         case SPMV_PANEL:
             if (!h->plan_panel.ready) { set_error("spmv_csr_plan_get: panel is not planned"); return SPMV_ERR_NOT_PLANNED; }
             params[4] = h->plan_panel.pw_bits; params[5] = h->plan_panel.waves_per_launch;
+            params[6] = h->plan_panel.lds_mode ? 2 : 1;
             return SPMV_OK;
         default: set_error("spmv_csr_plan_get: unknown variant %d", variant); return SPMV_ERR_VARIANT;
     }
@@ -420,7 +421,7 @@ int spmv_csr_plan_set(spmv_csr_t *h, int variant, const int32_t params[8], void 
         }
         case SPMV_ADAPTIVE: rc = plan_adaptive_with(*h, params[1], s); break;
         case SPMV_TILED: rc = plan_tiled_with(*h, params[1], params[2], params[3] != 0, s); break;
-        case SPMV_PANEL: rc = plan_panel_with(*h, params[4], params[5], s); break;
+        case SPMV_PANEL: rc = plan_panel_with(*h, params[4], params[5], params[6], s); break;
         case SPMV_XSKIP: rc = plan_xskip(*h, s); break;
         default: set_error("spmv_csr_plan_set: unknown variant %d", target); return SPMV_ERR_VARIANT;
     }
@@ -469,9 +470,9 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
     const ChunkPlan *p = variant == SPMV_ADAPTIVE ? &h->plan_adaptive : (variant == SPMV_TILED ? &h->plan_tiled : nullptr);
     if (variant == SPMV_VECTOR) snprintf(buf, (size_t)n, "lanes_per_row=%d", h->vector_width);
     else if (variant == SPMV_PANEL && h->plan_panel.ready)
-        snprintf(buf, (size_t)n, "panel_columns=%d panels=%d row_blocks=%d waves_per_launch=%d launches=%d",
+        snprintf(buf, (size_t)n, "panel_columns=%d panels=%d row_blocks=%d waves_per_launch=%d launches=%d x_panels_in=%s",
                  1 << h->plan_panel.pw_bits, h->plan_panel.npanels, h->plan_panel.nblocks,
-                 h->plan_panel.waves_per_launch, panel_launches(h->plan_panel));
+                 h->plan_panel.waves_per_launch, panel_launches(h->plan_panel), h->plan_panel.lds_mode ? "LDS" : "L2");
     else if (variant == SPMV_XSKIP && h->plan_xskip.ready)
         snprintf(buf, (size_t)n, "output_blocks=%d segments=%d slabs_per_block=%d", h->plan_xskip.nblocks, h->plan_xskip.nseg,
                  h->plan_xskip.slabs);

@@ -72,20 +72,20 @@ __global__ void k_panel_cuts(int64_t rows, int64_t nnz, int nb, const int32_t *_
     }
     cut[b] = (int32_t)lo;
 }
-// a cut of more than kRw rows (a stretch of short or empty rows) is split evenly: nsub[b] pieces
-__global__ void k_panel_nsub(int nb, const int32_t *__restrict__ cut, int32_t *__restrict__ nsub)
+// a cut of more than `cap` rows (a stretch of short or empty rows) is split evenly: nsub[b] pieces
+__global__ void k_panel_nsub(int nb, int cap, const int32_t *__restrict__ cut, int32_t *__restrict__ nsub)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nb) nsub[b] = (cut[b + 1] - cut[b] + kRw - 1) / kRw;
+    if (b < nb) nsub[b] = (cut[b + 1] - cut[b] + cap - 1) / cap;
 }
-__global__ void k_panel_brow(int64_t rows, int nb, const int32_t *__restrict__ cut, const int32_t *__restrict__ off,
+__global__ void k_panel_brow(int64_t rows, int nb, int cap, const int32_t *__restrict__ cut, const int32_t *__restrict__ off,
                              const int32_t *__restrict__ total, int32_t *__restrict__ brow)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) brow[*total] = (int32_t)rows;
     if (b >= nb) return;
     const int len = cut[b + 1] - cut[b];
-    const int n = (len + kRw - 1) / kRw;
+    const int n = (len + cap - 1) / cap;
     if (n == 0) return;
     const int step = (len + n - 1) / n;
     for (int i = 0; i < n; ++i) brow[off[b] + i] = cut[b] + i * step;
@@ -372,6 +372,84 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
     for (int i = lane; i < n; i += kWave) y[row0 + i] = ys[i];
 }
 
+// ---- the same sweep with the panel of x staged in LDS (PanelPlan::lds_mode) -----------------------------------------
+// For a SMALL x (config 2: 4 MiB) the panel does not have to come through L2 gather by gather -- one 128-byte line per
+// nonzero, 0.28 T gathers/s at best (tools/ubench_gather.hip) -- every workgroup can copy ALL of x through its LDS,
+// 16 Ki columns at a time with 16-byte LDS-DMA loads (22-27 TB/s chip-wide, same tool), and gather from LDS.  That is
+// cols x 4 bytes of L2->LDS traffic per workgroup whatever it multiplies, so it pays when the workgroups are few and
+// the panels well filled.  MEASURED: it does not pay even there -- config 2 (uniform columns) 0.135 ms against 0.087 ms
+// for the L2 sweep above: 64 panel steps of a barrier, 64 KiB of DMA and ONE 64-nonzero instruction per wavefront each
+// expose a memory round trip per step (a deeper-pipelined form with the stream prefetched three groups ahead and the
+// tile bounds on the scalar unit measured 0.186 ms: the compiler parks the prefetched group behind the next panel's
+// DMA).  So the library never chooses this mode; it documents the experiment and stays selectable and tested.
+// Workgroup = 16 wavefronts, each with a row block of <= 384 rows whose sums live in its slice of LDS (same layout
+// and plan as above with 2^14-column panels); two panel buffers: panel p+1 streams in while panel p is multiplied,
+// one barrier per panel.  Lanes hold CONSECUTIVE nonzeros of the tile (rows ascend), equal rows are folded by a
+// segmented shuffle scan and the last lane of each run adds into LDS with a plain read-add-write -- no join bits, no
+// LDS atomics (0.33 lane-updates per clock, tools/ubench_lds_atomic.hip).
+constexpr int kLdsPwBits = 14;
+constexpr int kLdsW = 1 << kLdsPwBits;      // columns per staged panel: 64 KiB
+constexpr int kLdsWaves = 16;
+constexpr int kRwLds = 384;                 // most rows of a wavefront's block: 1.5 KiB of sums
+constexpr int kRwLdsTarget = 256;
+
+__global__ __launch_bounds__(kLdsWaves *kWave) void k_panel_lds(int nblocks, int64_t cols, const int32_t *__restrict__ brow,
+                                                                 const int32_t *__restrict__ tile_ptr,
+                                                                 const uint32_t *__restrict__ packed,
+                                                                 const float *__restrict__ pvals,
+                                                                 const float *__restrict__ x, float *__restrict__ y, int np)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *ys = lds + 2 * kLdsW + w * kRwLds;
+    const int wb = blockIdx.x * kLdsWaves + w;
+    const bool live = wb < nblocks;                         // wave-uniform; idle wavefronts still stage and meet the barriers
+    const int row0 = live ? brow[wb] : 0, row1 = live ? brow[wb + 1] : 0;
+    const int n = row1 - row0;
+    for (int i = lane; i < kRwLds; i += kWave) ys[i] = 0.0f;
+    const int32_t *tp = tile_ptr + (int64_t)(live ? wb : 0) * (np + 1);
+
+    auto stage = [&](int p) {
+        float *dst = lds + (p & 1) * kLdsW;
+        const int64_t g0 = (int64_t)p << kLdsPwBits;
+        if (g0 + kLdsW + 3 < cols) {                        // workgroup-uniform
+#pragma unroll
+            for (int i = tid * 4; i < kLdsW; i += kLdsWaves * kWave * 4) __builtin_amdgcn_global_load_lds(x + g0 + i, dst + i, 16, 0, 0);
+        } else {
+            for (int i = tid; i < kLdsW; i += kLdsWaves * kWave) dst[i] = g0 + i < cols ? x[g0 + i] : 0.0f;
+        }
+    };
+    stage(0);
+    for (int p = 0; p < np; ++p) {
+        __builtin_amdgcn_s_waitcnt(0);                      // this lane's pieces of panel p (and its stream loads) have landed
+        __syncthreads();                                    // ... everyone's; and everyone is done reading buffer (p+1)&1
+        if (p + 1 < np) stage(p + 1);
+        if (!live) continue;
+        const float *xp = lds + (p & 1) * kLdsW;
+        const int k0 = tp[p], k1 = tp[p + 1];
+        for (int kb = k0; kb < k1; kb += kWave) {
+            const int k = kb + lane;
+            const bool on = k < k1;
+            const uint32_t word = on ? packed[k] : 0xFFFFFFFFu;
+            const float v = on ? pvals[k] : 0.0f;
+            const int row = (int)(word >> kRowShift);       // off lanes: a row id no real row has
+            float prod = on ? v * xp[word & (kLdsW - 1)] : 0.0f;
+            // rows ascend inside a tile: fold the runs of equal rows (inclusive segmented scan), the last lane of a run adds
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const float t = __shfl_up(prod, d, kWave);
+                const int r = __shfl_up(row, d, kWave);
+                if (lane >= d && r == row) prod += t;
+            }
+            const int next = __shfl_down(row, 1, kWave);
+            if (on && (lane == kWave - 1 || next != row)) ys[row] += prod;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += kWave) y[row0 + i] = ys[i];
+}
+
 int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -393,12 +471,25 @@ void destroy_panel(PanelPlan &p)
 // one launch = one set of co-resident waves sweeping in step: 2 workgroups (4 waves) per CU
 static int resident_waves(int device) { return device_cus(device) * 2 * kWavesPerWg; }
 
-int plan_panel(spmv_csr &h, hipStream_t s) { return plan_panel_with(h, 0, 0, s); }
+// spmv_csr_plan: idempotent like the other variants (spmv_csr_plan_set always re-plans: the way to refresh the copied values)
+int plan_panel(spmv_csr &h, hipStream_t s) { return h.plan_panel.ready ? SPMV_OK : plan_panel_with(h, 0, 0, 0, s); }
 
-int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, hipStream_t s)
+// want_mode: 0 = the rule below, 1 = panels through L2 (k_panel), 2 = panels staged in LDS (k_panel_lds)
+int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, hipStream_t s)
 {
     destroy_panel(h.plan_panel);
     PanelPlan p;
+    {
+        // LDS mode (k_panel_lds) is never chosen by the library: it was built to test whether staging the panels of a
+        // SMALL x in LDS beats gathering them through L2 and measured slower where it had
+        // its best chance -- config 2, uniform columns: 0.135 ms against 0.087 ms; config 3: 3.5 ms against 0.86 ms
+        // ("Uniform columns").  It stays selectable (params[6] = 2, SPMV_PANEL_LDS=1) and tested.
+        bool lds = false;
+        if (const char *e = getenv("SPMV_PANEL_LDS")) lds = atoi(e) != 0;
+        if (want_mode == 1) lds = false;
+        if (want_mode == 2) lds = true;
+        p.lds_mode = lds;
+    }
     if (h.nnz > (int64_t)INT_MAX - 4 * kStep) {
         set_error("spmv_csr_plan(panel): nnz %lld too close to 2^31 for one handle", (long long)h.nnz);
         return SPMV_ERR_INVALID;
@@ -409,6 +500,14 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, hipStream_t s)
     if (bits < 8) bits = 8;
     if (bits > kColBits) bits = kColBits;
     while (bits < kColBits && ((h.cols + (1ll << bits) - 1) >> bits) > kMaxPanels) ++bits;
+    if (p.lds_mode) {
+        bits = kLdsPwBits;
+        if (((h.cols + kLdsW - 1) >> kLdsPwBits) > kMaxPanels) {
+            set_error("spmv_csr_plan(panel, LDS mode): %lld columns need more than %d panels of 2^%d columns", (long long)h.cols,
+                      kMaxPanels, kLdsPwBits);
+            return SPMV_ERR_INVALID;
+        }
+    }
     p.pw_bits = bits;
     p.npanels = (int)((h.cols + (1ll << bits) - 1) >> bits);
     if (p.npanels < 1) p.npanels = 1;
@@ -424,6 +523,7 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, hipStream_t s)
         if (v > 0) p.waves_per_launch = v;
     }
     if (want_waves > 0) p.waves_per_launch = want_waves;
+    if (p.lds_mode) p.waves_per_launch = device_cus(h.device) * kLdsWaves;   // one 16-wavefront workgroup per CU and round
     if (h.rows == 0) {
         p.ready = true;
         h.plan_panel = p;
@@ -432,6 +532,8 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, hipStream_t s)
     const int64_t launches0 =
         (h.rows + (int64_t)p.waves_per_launch * kRwTarget - 1) / ((int64_t)p.waves_per_launch * kRwTarget);
     int64_t nb0 = launches0 * p.waves_per_launch;
+    const int cap = p.lds_mode ? kRwLds : kRw;
+    if (p.lds_mode) nb0 = (h.rows + kRwLdsTarget - 1) / kRwLdsTarget;
     if (nb0 > h.rows) nb0 = h.rows;
     DevPtr<int32_t> cut, nsub, total, brow;
     SPMV_HIP_TRY(cut.alloc((size_t)nb0 + 1));
@@ -441,7 +543,7 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, hipStream_t s)
     k_panel_cuts<<<dim3(gb), dim3(256), 0, s>>>(h.rows, h.nnz, (int)nb0, h.d_row_ptr, cut.p);
     int rc = check_launch("k_panel_cuts");
     if (rc) return rc;
-    k_panel_nsub<<<dim3(gb), dim3(256), 0, s>>>((int)nb0, cut.p, nsub.p);
+    k_panel_nsub<<<dim3(gb), dim3(256), 0, s>>>((int)nb0, cap, cut.p, nsub.p);
     if ((rc = check_launch("k_panel_nsub"))) return rc;
     if ((rc = exclusive_scan_i32(nsub.p, nb0, total.p, s))) return rc;
     int32_t nblocks = 0;
@@ -449,7 +551,7 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, hipStream_t s)
     SPMV_HIP_TRY(hipStreamSynchronize(s));
     p.nblocks = nblocks;
     SPMV_HIP_TRY(brow.alloc((size_t)p.nblocks + 1));
-    k_panel_brow<<<dim3(gb), dim3(256), 0, s>>>(h.rows, (int)nb0, cut.p, nsub.p, total.p, brow.p);
+    k_panel_brow<<<dim3(gb), dim3(256), 0, s>>>(h.rows, (int)nb0, cap, cut.p, nsub.p, total.p, brow.p);
     if ((rc = check_launch("k_panel_brow"))) return rc;
 
     DevPtr<uint32_t> packed;
@@ -473,9 +575,11 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, hipStream_t s)
             p.nblocks, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, p.pw_bits, p.npanels, tiles.p, packed.p,
             pvals.p);
         if ((rc = check_launch("k_panel_fill"))) return rc;
-        k_panel_joins<<<dim3((unsigned)p.nblocks), dim3(256), 0, s>>>(brow.p, p.npanels, h.d_row_ptr, tiles.p,
-                                                                       packed.p);
-        if ((rc = check_launch("k_panel_joins"))) return rc;
+        if (!p.lds_mode) {   // the LDS kernel folds equal rows itself
+            k_panel_joins<<<dim3((unsigned)p.nblocks), dim3(256), 0, s>>>(brow.p, p.npanels, h.d_row_ptr, tiles.p,
+                                                                           packed.p);
+            if ((rc = check_launch("k_panel_joins"))) return rc;
+        }
     }
     SPMV_HIP_TRY(hipStreamSynchronize(s));   // the temporaries are freed on return
     p.d_packed = packed.release();
@@ -489,6 +593,7 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, hipStream_t s)
 
 int panel_launches(const PanelPlan &p)
 {
+    if (p.lds_mode) return p.nblocks ? 1 : 0;
     return p.nblocks && p.waves_per_launch ? (p.nblocks + p.waves_per_launch - 1) / p.waves_per_launch : 0;
 }
 
@@ -498,6 +603,15 @@ int launch_panel(const spmv_csr &h, const float *x, float *y, hipStream_t s)
     if (!p.ready) {
         set_error("spmv_csr_run: variant panel is not planned (call spmv_csr_plan first)");
         return SPMV_ERR_NOT_PLANNED;
+    }
+    if (p.lds_mode) {
+        if (p.nblocks == 0) return SPMV_OK;
+        const size_t lds = sizeof(float) * (size_t)(2 * kLdsW + kLdsWaves * kRwLds);
+        static LdsOptIn optin;
+        if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_panel_lds), h.device, (int)lds)) return rc;
+        k_panel_lds<<<dim3((unsigned)((p.nblocks + kLdsWaves - 1) / kLdsWaves)), dim3(kLdsWaves * kWave), lds, s>>>(
+            p.nblocks, h.cols, p.d_brow, p.d_tile_ptr, p.d_packed, p.d_pvals, x, y, p.npanels);
+        return check_launch("k_panel_lds");
     }
     // equal shares: 1536 blocks on 1024 slots run as 768 + 768, not 1024 + 512
     const int launches = panel_launches(p);

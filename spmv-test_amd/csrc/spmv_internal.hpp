@@ -91,6 +91,7 @@ struct ChunkPlan {
 // SPMV_PANEL (kernels_panel.hip): row blocks of at most 8192 rows and equal nonzero counts, each block's nonzeros stably sorted by column panel.
 struct PanelPlan {
     bool ready = false;
+    bool lds_mode = false;         // panels of 2^14 columns staged in LDS by 16-wavefront workgroups (small x) instead of gathered through L2
     int pw_bits = 0;               // log2(columns per panel)
     int npanels = 0;
     int nblocks = 0;               // row blocks (<= 8192 rows, equal nonzero counts) = wavefronts of work
@@ -156,7 +157,7 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s);
 // TILED with exactly these parameters (spmv_csr_plan_set); block 256|512|1024, maxpass >= 1
 int plan_tiled_with(spmv_csr &h, int block, int maxpass, bool col16, hipStream_t s);
 int plan_adaptive_with(spmv_csr &h, int block, hipStream_t s);
-int plan_panel_with(spmv_csr &h, int pw_bits, int waves_per_launch, hipStream_t s);   // 0 = library default
+int plan_panel_with(spmv_csr &h, int pw_bits, int waves_per_launch, int mode, hipStream_t s);   // 0 = library default
 void destroy_plans(spmv_csr &h);
 
 int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out);

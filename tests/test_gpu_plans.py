@@ -203,3 +203,51 @@ def test_sorted_chunks_reproduce_the_staged_result_bit_for_bit(pkg, oracle, gpu,
     assert np.array_equal(ys["0"].view(np.uint32), ys["3"].view(np.uint32))
     assert np.array_equal(ys["0"].view(np.uint32), ys["-1"].view(np.uint32))      # the default: sorted where modelled cheaper
     prob.A.close()
+
+
+# ---- the panel sweep with its x panels staged in LDS (small x) vs gathered through L2 --------------------------------
+@pytest.mark.parametrize("name,scale,band", [("c2", 1 / 4, 0), ("c3", 1 / 16, 0), ("c4", 1 / 16, 4096), ("c2", 1.0, 0)])
+def test_panel_in_lds_mode_matches_oracle_and_l2_mode(pkg, oracle, gpu, name, scale, band):
+    """PANEL mode 2 (params[6]): every workgroup copies x through LDS 16 Ki columns at a time; mode 1: the round-1 sweep
+    with L2-resident panels.  Both against the oracle; the library's own choice (mode 0) is the L2 sweep everywhere --
+    the LDS form measured slower even at config 2 (DESIGN.md section 4 "Uniform columns") and stays as the experiment."""
+    capi = pkg.capi
+    w = pkg.workloads.config(name, band=band, scale=scale)
+    prob = synth_problem(pkg, oracle, gpu, w)
+    y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+    for mode, tag in ((2, "x_panels_in=LDS"), (1, "x_panels_in=L2")):
+        prob.A.plan_set(capi.PANEL, [capi.PANEL, 0, 0, 0, 0, 0, mode, 0])
+        d = prob.A.plan_describe(capi.PANEL)
+        assert tag in d, d
+        y = prob.run(capi.PANEL)
+        assert_close_to_oracle(y, y64, mag, f"{w.name} panel {tag}")
+        assert prob.A.plan_params(capi.PANEL)[6] == mode
+    if name == "c2" and scale == 1.0:
+        prob.A.plan_set(capi.PANEL, [capi.PANEL, 0, 0, 0, 0, 0, 0, 0])
+        assert "x_panels_in=L2" in prob.A.plan_describe(capi.PANEL)
+    prob.A.close()
+
+
+def test_panel_lds_mode_edge_shapes(pkg, oracle, gpu):
+    """Columns not a multiple of the 16 Ki panel, fewer rows than one wavefront block, empty rows, one long row, and a
+    row block count that is not a multiple of 16 (idle wavefronts still stage and meet the barriers)."""
+    capi = pkg.capi
+    rng = np.random.Generator(np.random.PCG64(77))
+    for rows, cols, lens in ((5, 100, [3, 0, 7, 0, 1]), (1000, 50_001, None), (7000, 16_384 * 3 + 5, None), (300, 40_000, "long")):
+        if lens is None:
+            L = rng.integers(0, 40, size=rows)
+        elif lens == "long":
+            L = rng.integers(0, 6, size=rows); L[17] = 30_000
+        else:
+            L = np.asarray(lens)
+        L = np.minimum(L, cols)
+        rp = np.concatenate([[0], np.cumsum(L)]).astype(np.int32)
+        ci = np.concatenate([np.sort(rng.choice(cols, size=int(l), replace=False)) for l in L] + [np.zeros(0, np.int64)]).astype(np.int32)
+        va = rng.uniform(-1, 1, size=len(ci)).astype(np.float32)
+        x = rng.uniform(-1, 1, size=cols).astype(np.float32)
+        prob = DeviceProblem(pkg, gpu, rows, cols, rp, ci, va, x)
+        prob.A.plan_set(capi.PANEL, [capi.PANEL, 0, 0, 0, 0, 0, 2, 0])
+        y = prob.run(capi.PANEL)
+        y64, mag = oracle.spmv_f64(rp, ci, va, x)
+        assert_close_to_oracle(y, y64, mag, f"panel LDS {rows}x{cols}")
+        prob.A.close()
