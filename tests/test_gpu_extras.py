@@ -82,7 +82,9 @@ def test_panel_plan_copies_the_values(pkg, oracle, gpu):
     prob.A.run(pkg.capi.PANEL, prob.d_x, prob.d_y)
     torch.cuda.synchronize()
     assert np.array_equal(prob.d_y[:w.rows].cpu().numpy(), y0)                 # still the planned values
-    y1 = prob.run(pkg.capi.PANEL)                                              # run() plans again
+    assert np.array_equal(prob.run(pkg.capi.PANEL), y0)                        # spmv_csr_plan is idempotent: still the copy
+    prob.A.plan_set(pkg.capi.PANEL, prob.A.plan_params(pkg.capi.PANEL))       # spmv_csr_plan_set always re-plans
+    y1 = prob.run(pkg.capi.PANEL)
     assert np.array_equal(y1, 2.0 * y0)
     assert np.array_equal(prob.run(pkg.capi.TILED).view(np.uint32), prob.run(pkg.capi.TILED).view(np.uint32))
 
