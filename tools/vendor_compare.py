@@ -31,6 +31,7 @@ WORKLOADS = [
     ("c3", dict(rows=4 << 20, dist="powerlaw", mean=32, band=8192)),
     ("c4", dict(rows=16 << 20, dist="mixed", mean=16, band=0)),
     ("c4", dict(rows=16 << 20, dist="mixed", mean=16, band=8192)),
+    ("c4", dict(rows=16 << 20, dist="mixed", mean=16, band=65536)),
 ]
 
 
@@ -98,7 +99,7 @@ def main():
 
         A = capi.CsrMatrix.from_device(w.rows, w.cols, d_rp, d_ci, d_va)
         ours = {}
-        for vname in ("scalar", "wave", "adaptive", "tiled", "panel"):
+        for vname in ("scalar", "wave", "adaptive", "tiled", "panel", "auto"):
             v = capi.VARIANTS[vname]
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -110,6 +111,7 @@ def main():
             ours[vname] = ms
             emit(workload=label, impl=f"this:{vname}", ms=round(ms, 4), GBs=round(B / ms / 1e6, 1),
                  pct_of_8TBs=round(B / ms / 1e6 / 80, 2), preprocess_ms=round(plan_ms, 3))
+        emit(workload=label, impl="this:auto choice", plan=A.plan_describe(capi.AUTO)[:60])
         best_ours = min(ours, key=ours.get)
         ours["best"] = ours[best_ours]
         A.run(capi.TILED, d_x, d_y)
@@ -161,7 +163,8 @@ def main():
             emit(workload=label, impl=f"rocsparse:{aname}", ms=round(best, 4), GBs=round(B / best / 1e6, 1),
                  pct_of_8TBs=round(B / best / 1e6 / 80, 2), preprocess_ms=round(prep_ms, 3),
                  workspace_bytes=int(size.value), max_abs_diff_vs_this=diff,
-                 this_tiled_speedup=round(best / ours["tiled"], 2), this_best=best_ours,
+                 this_tiled_speedup=round(best / ours["tiled"], 2), this_auto_speedup=round(best / ours["auto"], 2),
+                 this_best=best_ours,
                  this_best_speedup=round(best / ours["best"], 2))
             del buf
             torch.cuda.synchronize()
