@@ -58,6 +58,8 @@ def parse():
                     help="weak (default): 16Mi rows per rank, the matrix grows with N; strong: config 5's (128Mi)^2 matrix "
                          "for every N (--total-blocks row blocks dealt over the ranks)")
     ap.add_argument("--total-blocks", type=int, default=32, help="--scaling strong: row blocks of the fixed matrix")
+    ap.add_argument("--exchange", default=os.environ.get("SPMV_BENCH_EXCHANGE", "allgather"), choices=["allgather", "p2p"],
+                    help="N>1: concatenate y with RCCL's all-gather (default) or with one direct send/recv pair per peer")
     ap.add_argument("--backend", default=os.environ.get("SPMV_BENCH_BACKEND", "nccl"),
                     help="nccl (= RCCL, default) | gloo (rehearsal of the N>1 path with ranks sharing one GPU)")
     return ap.parse_args()
@@ -170,7 +172,7 @@ def main():
     else:
         def bind(h):
             return lambda x, y: h.run(variant, x, y)
-        sh = pkg.dist.PipelinedSpmv(S, sub_rows, w.cols, [bind(h) for h in handles], dev)
+        sh = pkg.dist.PipelinedSpmv(S, sub_rows, w.cols, [bind(h) for h in handles], dev, exchange=args.exchange)
         if rank == 0:
             capi.synth_x(w.seed, 0, w.cols, sh.x)
         if world > 1:
@@ -285,6 +287,7 @@ def main():
                        "rows_per_gpu": rows_local, "nnz_per_gpu": nnz_local,
                        "parallelism": "single GPU" if world == 1 and not strong else
                        f"{S} block-cyclic row blocks per rank x{world} ranks, all-gather(y) of group s "
+                       f"({'RCCL all_gather' if args.exchange == 'allgather' else 'direct send/recv per peer'}) "
                        f"overlapped with the multiply of block s+1, {args.backend}",
                        "devices": (f"{world} ranks on {min(world, max(ndev, 1))} device(s)" +
                                    ("" if ndev >= world and args.backend == "nccl" else

@@ -96,7 +96,7 @@ struct PanelPlan {
     int npanels = 0;
     int nblocks = 0;               // row blocks (<= 8192 rows, equal nonzero counts) = wavefronts of work
     int waves_per_launch = 0;      // what is resident at once: one launch = one sweep in step
-    uint32_t *d_packed = nullptr;  // [nnz + slack] row_in_block << 19 | column_in_panel
+    uint32_t *d_packed = nullptr;  // [nnz + slack] row_in_block << 18 | join << 17 | column_in_panel (kernels_panel.hip)
     float *d_pvals = nullptr;      // [nnz + slack] values in the same order (a COPY: re-plan after changing vals)
     int32_t *d_tile_ptr = nullptr; // [nblocks * (npanels + 1)]
     int32_t *d_brow = nullptr;     // [nblocks + 1] first row of every block

@@ -80,6 +80,17 @@ class ShardedSpmv:
         return self.gather()
 
 
+class _Works:
+    """The works of one batched isend/irecv, waited for as one."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class PipelinedSpmv:
     """Block-cyclic row blocks with the all-gather of one block group overlapped with the multiply
     of the next (SURVEY section 8e "Overlap").
@@ -97,8 +108,15 @@ class PipelinedSpmv:
     CURRENT stream (the product binds ``CsrMatrix.run`` of one handle per block).
     """
 
-    def __init__(self, S: int, sub_rows: int, cols: int, local_spmvs, device, group=None):
+    def __init__(self, S: int, sub_rows: int, cols: int, local_spmvs, device, group=None, exchange: str = "allgather"):
         self.group = group
+        # how a block group is concatenated: "allgather" = one in-place all_gather_into_tensor (RCCL's collective: rings
+        # over the xGMI mesh); "p2p" = one batched isend/irecv pair per peer (grouped ncclSend/ncclRecv: every slice
+        # travels its owner's DIRECT link to each peer -- the all-pairs schedule of SURVEY section 5, 7 links busy at
+        # once).  Same bytes, same result; which is faster is for an 8-GPU node to say (bench.py --exchange).
+        if exchange not in ("allgather", "p2p"):
+            raise ValueError("exchange must be 'allgather' or 'p2p'")
+        self.exchange = exchange
         # one process, no process group: every block is local and nothing is exchanged (bench --scaling strong, N = 1)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -145,6 +163,15 @@ class PipelinedSpmv:
             dist.all_gather_into_tensor(host, mine.cpu(), group=self.group)
             grp.copy_(host)
             return None
+        if self.exchange == "p2p":
+            ops = []
+            for peer in range(self.world):
+                if peer == self.rank:
+                    continue
+                slot = grp[peer * self.sub_rows:(peer + 1) * self.sub_rows]
+                ops.append(dist.P2POp(dist.isend, mine, peer, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, slot, peer, group=self.group))
+            return _Works(dist.batch_isend_irecv(ops))
         src = mine if self.cuda else mine.clone()
         return dist.all_gather_into_tensor(grp, src, group=self.group, async_op=True)
 

@@ -75,7 +75,7 @@ def test_row_block_exchange(built, world, balanced):
     assert all(r[2] == (not balanced) for r in res)      # equal rows -> in-place gather path
 
 
-def _worker_pipe(rank, world, port, S, q):
+def _worker_pipe(rank, world, port, S, q, exchange="allgather"):
     import __graft_entry__ as ge
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -96,7 +96,7 @@ def _worker_pipe(rank, world, port, S, q):
             rp, ci, va = blocks[s]
             return lambda x, y: y.copy_(torch.from_numpy(orc.spmv(rp, ci, va, x.numpy())))
 
-        sh = pkg.dist.PipelinedSpmv(S, sub, w.cols, [make(s) for s in range(S)], torch.device("cpu"))
+        sh = pkg.dist.PipelinedSpmv(S, sub, w.cols, [make(s) for s in range(S)], torch.device("cpu"), exchange=exchange)
         assert sh.owned_blocks() == [s * world + rank for s in range(S)]
         if rank == 0:
             sh.x.copy_(torch.from_numpy(orc.synth_x(w.seed, 0, w.cols)))
@@ -126,3 +126,20 @@ def test_two_rank_block_cyclic_pipelined_exchange(built, S):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert [r[1] for r in res] == [True, True]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_block_cyclic_exchange_by_direct_send_recv(built, world):
+    """The same pipeline with the block groups concatenated by one isend/irecv pair per peer (bench.py --exchange p2p:
+    the all-pairs schedule over the direct xGMI links) instead of the all-gather collective: bit-exact, world 2 and 3."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipe, args=(r, world, port, 2, q, "p2p")) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert [r[1] for r in res] == [True] * world
