@@ -396,11 +396,20 @@ def main():
                     auto = (Ae.plan_describe(v).split(":")[0], ms)
                 if best is None or ms < best[1]:
                     best = (vn, ms)
+            # the kernel BASELINE.json's config string names for this config, timed beside the library's choice
+            named = {"c2": ("scalar",), "c3": ("wave", "wave_pipe")}.get(cname, ())
+            named_out = {}
+            for vn in named:
+                v = capi.VARIANTS[vn]
+                Ae.plan(v)
+                Ae.time(v, e_x, e_y, 2)
+                ms = min(Ae.time(v, e_x, e_y, 10) for _ in range(2))
+                named_out[vn] = {"kernel_ms": round(ms, 5), "frac_of_peak": round(be / ms / 1e6 / HBM_PEAK_GBS, 4)}
             extras.append({"workload": label, "auto": auto[0], "auto_kernel_ms": round(auto[1], 5),
                            "auto_frac_of_peak": round(be / auto[1] / 1e6 / HBM_PEAK_GBS, 4),
                            "best_variant": best[0], "best_kernel_ms": round(best[1], 5),
                            "best_frac_of_peak": round(be / best[1] / 1e6 / HBM_PEAK_GBS, 4),
-                           "algorithmic_bytes": be})
+                           "algorithmic_bytes": be, **({"config_named_kernel": named_out} if named_out else {})})
             Ae.close()
             del e_rp, e_ci, e_va, e_x, e_y
             torch.cuda.empty_cache()
