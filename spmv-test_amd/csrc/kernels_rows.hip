@@ -208,7 +208,21 @@ __global__ __launch_bounds__(kBlock) void k_wave_bundle(int64_t rows, const int3
         }
         const int i1 = i0 + cnt;
         const int32_t se = __shfl(e, i1 - 1);
-        for (int32_t k = sb + lane; k < se; k += kWave) prod[k - sb] = vals[k] * x[col_idx[k]];
+        {
+            // four 64-wide slices per trip: 8 streamed loads, then 4 gathers, are issued before the first use (the
+            // pipelining wsp_kernel_v1 adds to v0, wsp.cu:78-134, at wave64 width)
+            int32_t k = sb + lane;
+            for (; k + 3 * kWave < se; k += 4 * kWave) {
+                const int32_t c0 = col_idx[k], c1 = col_idx[k + kWave], c2 = col_idx[k + 2 * kWave], c3 = col_idx[k + 3 * kWave];
+                const float v0 = vals[k], v1 = vals[k + kWave], v2 = vals[k + 2 * kWave], v3 = vals[k + 3 * kWave];
+                const float x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+                prod[k - sb] = v0 * x0;
+                prod[k - sb + kWave] = v1 * x1;
+                prod[k - sb + 2 * kWave] = v2 * x2;
+                prod[k - sb + 3 * kWave] = v3 * x3;
+            }
+            for (; k < se; k += kWave) prod[k - sb] = vals[k] * x[col_idx[k]];
+        }
         const bool mine = lane >= i0 && lane < i1;
         const bool is_long = mine && e - b > kWave;
         if (mine && !is_long) {
