@@ -5,6 +5,10 @@
 set -e
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q                                              # parity: the first gate
+# the same parity files with every chunk sorted / every panel plan in LDS mode / round 1's timed plans
+SPMV_SORTED_FROM=1 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random_structures.py tests/test_gpu_extras.py tests/test_file_io.py -m gpu -x -q
+SPMV_PANEL_LDS=1 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random_structures.py tests/test_gpu_extras.py -m gpu -x -q
+SPMV_AUTOTUNE=1 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random_structures.py -m gpu -x -q
 python bench.py > gpurun_out/r02_bench_full.json                                 # -> profiles/r02_bench_n1_full.json
 bash tools/profile.sh r02                                                        # headline: kernel stats + FETCH/WRITE passes
 bash tools/profile.sh r02_band65536 "--band 65536"
