@@ -101,6 +101,14 @@ def test_panel_refuses_more_columns_than_its_format_holds(pkg, gpu):
         A.plan(capi.PANEL)
     assert e.value.status == capi.ERR_INVALID and "panels" in str(e.value)
     A.plan(capi.TILED)            # the other variants take it
+    A.plan(capi.AUTO)             # ... and SPMV_AUTO falls back to TILED where the panel layout cannot hold the matrix
+    assert A.plan_describe(capi.AUTO).startswith("auto -> tiled")
+    x = torch.zeros(1 << 30, dtype=torch.float32, device=gpu)
+    x[5] = 2.0; x[(1 << 30) - 1] = 3.0
+    y = torch.full((2,), float("nan"), device=gpu)
+    A.run(capi.AUTO, x, y)
+    torch.cuda.synchronize()
+    assert y.tolist() == [2.0, 3.0]
     A.close()
 
 
