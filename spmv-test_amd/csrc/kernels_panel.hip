@@ -35,8 +35,16 @@ namespace spmv {
 
 namespace {
 
-constexpr int kRwTarget = 8192;            // rows per wave block the launch count is sized for
-constexpr int kRw = 9728;                  // most rows of one block (equal-nonzero cuts vary): 38 KiB of LDS per wave
+// (the SPMV_PANEL_* macros exist for A/B builds, tools/explore.py; the shipped values are the defaults)
+#ifndef SPMV_PANEL_RW
+#define SPMV_PANEL_RW 9728
+#endif
+#ifndef SPMV_PANEL_WG_PER_CU
+#define SPMV_PANEL_WG_PER_CU 2
+#endif
+constexpr int kRw = SPMV_PANEL_RW;         // most rows of one block (equal-nonzero cuts vary): 38 KiB of LDS per wave
+constexpr int kRwTarget = kRw == 9728 ? 8192 : kRw * 27 / 32;   // rows per wave block the launch count is sized for
+constexpr int kWgPerCu = SPMV_PANEL_WG_PER_CU;   // workgroups of two wavefronts resident per CU: 2 x 76 KiB of LDS
 constexpr int kColBits = 17;               // column_in_panel field of packed[]
 constexpr unsigned kColMask = (1u << kColBits) - 1;
 constexpr unsigned kJoinBit = 1u << kColBits;   // this nonzero and the one 4 places before it in its tile share a row
@@ -469,7 +477,7 @@ void destroy_panel(PanelPlan &p)
 }
 
 // one launch = one set of co-resident waves sweeping in step: 2 workgroups (4 waves) per CU
-static int resident_waves(int device) { return device_cus(device) * 2 * kWavesPerWg; }
+static int resident_waves(int device) { return device_cus(device) * kWgPerCu * kWavesPerWg; }
 
 // spmv_csr_plan: idempotent like the other variants (spmv_csr_plan_set always re-plans: the way to refresh the copied values)
 int plan_panel(spmv_csr &h, hipStream_t s) { return h.plan_panel.ready ? SPMV_OK : plan_panel_with(h, 0, 0, 0, s); }
