@@ -422,7 +422,7 @@ int spmv_csr_plan_set(spmv_csr_t *h, int variant, const int32_t params[8], void 
         case SPMV_ADAPTIVE: rc = plan_adaptive_with(*h, params[1], s); break;
         case SPMV_TILED: rc = plan_tiled_with(*h, params[1], params[2], params[3] != 0, s); break;
         case SPMV_PANEL: rc = plan_panel_with(*h, params[4], params[5], params[6], s); break;
-        case SPMV_XSKIP: rc = plan_xskip(*h, s); break;
+        case SPMV_XSKIP: destroy_xskip(h->plan_xskip); rc = plan_xskip(*h, s); break;   // always rebuilt: the values are a copy
         default: set_error("spmv_csr_plan_set: unknown variant %d", target); return SPMV_ERR_VARIANT;
     }
     if (rc == SPMV_OK && variant == SPMV_AUTO) h->auto_variant = target;

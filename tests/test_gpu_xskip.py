@@ -63,3 +63,17 @@ def test_xskip_refuses_what_it_is_not_made_for(pkg, oracle, gpu):
     assert e.value.status == capi.ERR_INVALID and "duplicate" in str(e.value)
     assert prob.run(capi.SCALAR).tolist() == [3.0, 1.0]      # the other variants take duplicates
     prob.A.close()
+
+
+def test_xskip_plan_copies_the_values_and_plan_set_refreshes_them(pkg, oracle, gpu):
+    import torch
+    capi = pkg.capi
+    A, x = pkg.workloads.dense_random(512, 640, 0.5, seed=5)
+    rp, ci, va = oracle.csr_from_dense(A)
+    prob = DeviceProblem(pkg, gpu, 640, 512, rp, ci, va, x)
+    y0 = prob.run(capi.XSKIP)
+    prob.d_va.mul_(2.0)
+    assert np.array_equal(prob.run(capi.XSKIP), y0)                    # spmv_csr_plan is idempotent: the planned copy
+    prob.A.plan_set(capi.XSKIP, prob.A.plan_params(capi.XSKIP))       # spmv_csr_plan_set rebuilds it
+    assert np.array_equal(prob.run(capi.XSKIP), 2.0 * y0)
+    prob.A.close()
