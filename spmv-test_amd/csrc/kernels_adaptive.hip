@@ -770,7 +770,8 @@ __device__ __forceinline__ void sorted_body(float *smem, ChunkShared<BLOCK> &sh,
     constexpr unsigned kColMask = (1u << kColBits) - 1u;
 
     const int tid = threadIdx.x;
-    const int c = list[xcd_chunk(bid, nrun)];
+    const int ci = xcd_chunk(bid, nrun);          // position in the list of sorted chunks = slot of its words in perm[]
+    const int c = list[ci];
     const int64_t base = (int64_t)c * kChunkT;
     const int64_t lim = base + kChunkT;
     if (tid == 0) { sh.long_count = 0; sh.huge_count = 0; }
@@ -781,7 +782,7 @@ __device__ __forceinline__ void sorted_body(float *smem, ChunkShared<BLOCK> &sh,
     u4 pw[kVec];
     f4 vv[kVec];
     {
-        const u4 *p4 = reinterpret_cast<const u4 *>(perm + base);
+        const u4 *p4 = reinterpret_cast<const u4 *>(perm + (int64_t)ci * kChunkT);
         const f4 *v4 = reinterpret_cast<const f4 *>(vals + base);
 #pragma unroll
         for (int j = 0; j < kVec; ++j) pw[j] = __builtin_nontemporal_load(&p4[j * BLOCK + tid]);
@@ -833,7 +834,8 @@ __global__ __launch_bounds__(BLOCK, 8) void k_sorted(int64_t rows, int nrun, con
 // does not matter: the gathers of a line coalesce whatever their order, and no arithmetic depends on it).
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_plan_sorted(const int32_t *__restrict__ col_idx,
-                                                       const int32_t *__restrict__ win, uint32_t *__restrict__ perm)
+                                                       const int32_t *__restrict__ win, const int32_t *__restrict__ slot,
+                                                       uint32_t *__restrict__ perm)
 {
     constexpr int kChunkT = chunk_of(BLOCK);
     constexpr int kColBits = sorted_col_bits(BLOCK);
@@ -846,6 +848,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_sorted(const int32_t *__restrict
     if (!(win[2 * c + 1] & kSortedBit)) return;   // chunk-uniform
     const int w0 = win[2 * c];
     const int64_t base = (int64_t)c * kChunkT;
+    uint32_t *out = perm + (int64_t)slot[c] * kChunkT;   // perm[] holds the sorted chunks only, in list order
     for (int i = tid; i < kLines; i += BLOCK) hist[i] = 0;
     __syncthreads();
     for (int i = tid; i < kChunkT; i += BLOCK) atomicAdd(&hist[(col_idx[base + i] - w0) >> 5], 1);
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_sorted(const int32_t *__restrict
         // divmod(d / BLOCK, 4): the 64 lanes of ONE gather instruction then hold 64 CONSECUTIVE sorted elements (a
         // few neighbouring lines), not elements four apart whose lines the other three components would ask for again
         const int t = d % BLOCK, jq = d / BLOCK;
-        perm[base + ((jq >> 2) * BLOCK + t) * 4 + (jq & 3)] = ((unsigned)i << kColBits) | (unsigned)off;
+        out[((jq >> 2) * BLOCK + t) * 4 + (jq & 3)] = ((unsigned)i << kColBits) | (unsigned)off;
     }
 }
 
@@ -1277,9 +1280,9 @@ static int build_col16(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
 }
 
 template <int BLOCK>
-static int launch_plan_sorted(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
+static int launch_plan_sorted(const spmv_csr &h, ChunkPlan &p, const int32_t *d_slot, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_plan_sorted<BLOCK>), dim3(p.nchunks), dim3(BLOCK), 0, s, h.d_col_idx, p.d_win, p.d_perm);
+    hipLaunchKernelGGL((k_plan_sorted<BLOCK>), dim3(p.nchunks), dim3(BLOCK), 0, s, h.d_col_idx, p.d_win, d_slot, p.d_perm);
     return check_launch("k_plan_sorted");
 }
 
@@ -1318,10 +1321,11 @@ static int build_lists(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
                        p.d_list32);
     if ((rc = check_launch("k_plan_lists"))) return rc;
     if (ns > 0) {
-        SPMV_HIP_TRY(hipMalloc((void **)&p.d_perm, sizeof(uint32_t) * (size_t)chunk_of(p.block) * (size_t)p.nchunks));
-        if (p.block == 256) rc = launch_plan_sorted<256>(h, p, s);
-        else if (p.block == 512) rc = launch_plan_sorted<512>(h, p, s);
-        else rc = launch_plan_sorted<1024>(h, p, s);
+        // one slot of chunk words per SORTED chunk (fs.p: its rank among them, the order of list_sorted)
+        SPMV_HIP_TRY(hipMalloc((void **)&p.d_perm, sizeof(uint32_t) * (size_t)chunk_of(p.block) * (size_t)ns));
+        if (p.block == 256) rc = launch_plan_sorted<256>(h, p, fs.p, s);
+        else if (p.block == 512) rc = launch_plan_sorted<512>(h, p, fs.p, s);
+        else rc = launch_plan_sorted<1024>(h, p, fs.p, s);
         if (rc) return rc;
     }
     SPMV_HIP_TRY(hipStreamSynchronize(s));   // the scans' temporaries are freed on return

@@ -70,7 +70,7 @@ struct ChunkPlan {
     int32_t *d_list32 = nullptr;   // [nchunks - n16 - nsorted] the others, run by the 32-bit body
     int n16 = 0;
     // sorted chunks (TILED): spans of several LDS regions gather x in column order instead of staging it
-    uint32_t *d_perm = nullptr;        // [nchunks * chunk] position << 18 | column - w0, read INSTEAD of col_idx
+    uint32_t *d_perm = nullptr;        // [nsorted * chunk] position << 18 | column - w0 of the sorted chunks (list order), read INSTEAD of col_idx
     int32_t *d_list_sorted = nullptr;  // [nsorted]
     int nsorted = 0;                   // chunks run by the sorted body
     int nsorted_marked = 0;            // chunks the window pass marked (a few may still switch to a block list)
