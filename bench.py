@@ -360,7 +360,7 @@ def main():
         del A, d_rp, d_ci, d_va, d_x, d_y, handles, keep
         torch.cuda.empty_cache()
         extras = []
-        todo = [("c4", 0), ("c4", 2048), ("c4", 65536), ("c2", 0), ("c2", 8192), ("c3", 0), ("c3", 8192),
+        todo = [("c4", 0), ("c4", 2048), ("c4", 65536), ("c4", 200000), ("c2", 0), ("c2", 8192), ("c3", 0), ("c3", 8192),
                 ("c5", 8192), ("c5", 0)]
         for cname, band in todo:
             if cname == args.config and band == args.band:
