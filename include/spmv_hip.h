@@ -43,7 +43,10 @@ enum spmv_status {
     SPMV_ERR_HIP = -3,       /* a HIP runtime call failed (message has details)  */
     SPMV_ERR_VARIANT = -4,   /* unknown variant id (reference: silently no-op,   */
                              /* wsp.cu:187 -- here it is reported)               */
-    SPMV_ERR_NOT_PLANNED = -5
+    SPMV_ERR_NOT_PLANNED = -5,
+    SPMV_ERR_STALE_PLAN = -6 /* the variant's plan holds a COPY of vals taken before   */
+                             /* spmv_csr_values_changed (or, under SPMV_CHECK_VALUES=1,*/
+                             /* before the array changed): re-plan                     */
 };
 
 /* Kernel variants.  The right-hand column is the reference slot each one
@@ -86,7 +89,7 @@ enum spmv_variant {
                         /*   the `x_i != 0` skip of asp_kernel_v* (src/kernels/asp.cu:20-26), awsp_kernel_v1     */
                         /*   (awsp.cu:127-134), awsp_ref_kernel (awsp_ref.cu:52).  For dense-ish matrices (the    */
                         /*   reference's regime): the plan refuses when ceil(rows/1024) x cols exceeds 2^27, and  */
-                        /*   rows must be duplicate-free.  Its plan COPIES the values, like SPMV_PANEL.           */
+                        /*   rows must be sorted and duplicate-free.  Its plan COPIES the values, like PANEL.  */
     SPMV_VARIANT_COUNT = 9
 };
 
@@ -148,6 +151,17 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
  * overwritten.  No allocation, no synchronisation: graph-capturable. */
 SPMV_API int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream);
 SPMV_API int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void *stream);
+
+/* Tell the handle that the caller has rewritten vals (borrowed arrays, spmv_csr_create_device).  The variants that
+ * read vals live need nothing; the plans of SPMV_PANEL and SPMV_XSKIP hold a re-ordered COPY of the values, and from
+ * this call on spmv_csr_run of those variants (and of SPMV_AUTO where it resolved to one of them) fails with
+ * SPMV_ERR_STALE_PLAN instead of multiplying with the old values, until spmv_csr_plan (which rebuilds a stale plan
+ * with the parameters it had) or spmv_csr_plan_set has run again.  The library cannot see a write it is not told
+ * about; for hunting one down set SPMV_CHECK_VALUES=1 in the environment: plans then also keep a checksum of vals and
+ * every run of those variants recomputes it first (one pass over vals and a host wait per run -- a debug aid, not
+ * graph-capturable).  Runs of one handle must be stream-ordered: plans own scratch buffers (slab partials, carries)
+ * that two concurrent runs of the same handle on different streams would share. */
+SPMV_API int spmv_csr_values_changed(spmv_csr_t *h);
 
 /* What decides a plan's chunk cuts and with them the order of every fp32 sum, as numbers a caller can carry from
  * one handle to another (rank 0 to the other ranks of a job, one run to the next):

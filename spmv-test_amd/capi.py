@@ -25,7 +25,7 @@ VARIANTS = {"scalar": SCALAR, "wave": WAVE, "wave_pipe": WAVE_PIPE, "vector": VE
 ALL_VARIANTS = dict(VARIANTS, xskip=XSKIP)
 
 # enum spmv_status
-OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_VARIANT, ERR_NOT_PLANNED = 0, -1, -2, -3, -4, -5
+OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_VARIANT, ERR_NOT_PLANNED, ERR_STALE_PLAN = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/spmv_hip.h declares: name -> (restype, argtypes)
 _i32p, _f32p, _vp = C.c_void_p, C.c_void_p, C.c_void_p   # raw addresses (host or device)
@@ -45,6 +45,7 @@ SIGNATURES = {
     "spmv_csr_destroy": (C.c_int, [_H]),
     "spmv_csr_plan": (C.c_int, [_H, C.c_int, _vp]),
     "spmv_csr_run": (C.c_int, [_H, C.c_int, _f32p, _f32p, _vp]),
+    "spmv_csr_values_changed": (C.c_int, [_H]),
     "spmv_csr_plan_get": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int32)]),
     "spmv_csr_plan_set": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int32), _vp]),
     "spmv_csr_plan_like": (C.c_int, [_H, _H, C.c_int, _vp]),
@@ -191,6 +192,10 @@ class CsrMatrix:
         """Enqueue y = A x on torch's current stream (or ``stream``).  x, y: float32 device tensors."""
         assert x.numel() >= self.cols and y.numel() >= self.rows
         check(lib().spmv_csr_run(self._h, variant, _ptr(x), _ptr(y), _stream_handle(stream)))
+
+    def values_changed(self) -> None:
+        """The caller rewrote vals (borrowed arrays): plans that hold a copy of them are stale from here on."""
+        check(lib().spmv_csr_values_changed(self._h))
 
     def time(self, variant: int, x, y, iters: int, stream=None) -> float:
         """Mean ms per launch over ``iters`` launches, HIP events on the launch stream."""

@@ -301,6 +301,7 @@ static int plan_auto(spmv_csr &h, hipStream_t s)
         rc = plan_panel(h, s);
         if (rc == SPMV_OK) {
             h.auto_variant = SPMV_PANEL;
+            drop_tiled_plan(h);   // up to 6 bytes per nonzero of column copies nobody will read (spmv_csr_plan(TILED) rebuilds it)
             return SPMV_OK;
         }
         if (rc != SPMV_ERR_INVALID) return rc;   // INVALID: outside the panel layout's limits -> stay with TILED
@@ -359,6 +360,13 @@ int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void 
             set_error("spmv_csr_run: unknown variant %d", variant);
             return SPMV_ERR_VARIANT;
     }
+}
+
+int spmv_csr_values_changed(spmv_csr_t *h)
+{
+    if (!h) { set_error("spmv_csr_values_changed: null handle"); return SPMV_ERR_INVALID; }
+    ++h->values_gen;
+    return SPMV_OK;
 }
 
 int spmv_csr_plan_get(const spmv_csr_t *h, int variant, int32_t params[8])

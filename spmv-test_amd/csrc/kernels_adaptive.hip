@@ -1128,8 +1128,17 @@ static void free_plan(ChunkPlan &p)
 static int default_passes(int block) { return block == 1024 ? 12 : (block == 512 ? 4 : 2); }
 
 
-// chunk boundaries (+ column windows when `maxpass` > 0) for workgroups of `block` threads
+static int build_plan_impl(const spmv_csr &h, int block, int maxpass, hipStream_t s, ChunkPlan &p, int *single, int *full);
+
+// chunk boundaries (+ column windows when `maxpass` > 0) for workgroups of `block` threads; a failure leaves no plan
 static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, ChunkPlan &p, int *single, int *full)
+{
+    const int rc = build_plan_impl(h, block, maxpass, s, p, single, full);
+    if (rc) free_plan(p);
+    return rc;
+}
+
+static int build_plan_impl(const spmv_csr &h, int block, int maxpass, hipStream_t s, ChunkPlan &p, int *single, int *full)
 {
     const bool windows = maxpass > 0;
     free_plan(p);
@@ -1142,19 +1151,21 @@ static int build_plan(const spmv_csr &h, int block, int maxpass, hipStream_t s, 
     // needs 80 VGPRs -> 6 waves/SIMD, and lost 7-40 % against 8 waves/SIMD one-shot workgroups)
     if (const char *e = getenv("SPMV_PERSIST")) p.persist = atoi(e) != 0;
     // tuning knob SPMV_SORTED_FROM=n: chunks whose span needs n staging passes or more gather in column order
-    // instead (0 = never; default 3: measured)
+    // instead (0 = never; default -1: staged or sorted by the modelled cost of each chunk, PlanCost above)
     p.sorted_from = windows && !p.persist ? kSortedFromDefault : 0;
     if (const char *e = getenv("SPMV_SORTED_FROM")) {
         const int v = atoi(e);
         if (windows && !p.persist && v >= -1 && v <= 64) p.sorted_from = v;
     }
     PlanCost cost;
-    if (const char *e = getenv("SPMV_PLAN_COST")) {   // nine integers, the fields of PlanCost in order (calibration runs)
-        int v[9];
-        if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) == 9) {
+    if (const char *e = getenv("SPMV_PLAN_COST")) {   // the fields of PlanCost in order (calibration runs): nine or all ten
+        int v[10];
+        const int got = sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8], &v[9]);
+        if (got >= 9) {
             cost.c16_base = v[0]; cost.c16_pass = v[1]; cost.c32_base = v[2]; cost.c32_pass = v[3];
             cost.sorted_base = v[4]; cost.sorted_line_512 = v[5]; cost.sorted_line_1024 = v[6]; cost.sorted_few_rows = v[7];
             cost.unstaged = v[8];
+            if (got == 10) cost.long_piece = v[9];
         }
     }
     const int chunk = chunk_of(block);
@@ -1335,10 +1346,15 @@ static int build_lists(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
 int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s);
 
 // 16-bit column copy (where it pays) and the chunk lists of the plan in h.plan_tiled
+// A failure (an allocation of the 2-4 bytes per nonzero these copies take) leaves NO plan behind: k_plan_col16 may
+// already have rewritten win[] for columns that then never got their list, and a later spmv_csr_plan must not take the
+// half-built plan for a finished one.
 static int finish_tiled(spmv_csr &h, bool col16, hipStream_t s)
 {
     int rc = col16 ? build_col16(h, h.plan_tiled, s) : SPMV_OK;
-    return rc ? rc : build_lists(h, h.plan_tiled, s);
+    if (rc == SPMV_OK) rc = build_lists(h, h.plan_tiled, s);
+    if (rc) free_plan(h.plan_tiled);
+    return rc;
 }
 
 int plan_tiled_with(spmv_csr &h, int block, int maxpass, bool col16, hipStream_t s)
@@ -1521,6 +1537,8 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
     if ((rc = build_plan(h, best.block, best.maxpass, s, h.plan_tiled, nullptr, nullptr))) return rc;
     return finish_tiled(h, best.narrow != 0, s);
 }
+
+void drop_tiled_plan(spmv_csr &h) { free_plan(h.plan_tiled); }
 
 void destroy_plans(spmv_csr &h)
 {

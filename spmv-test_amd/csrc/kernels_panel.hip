@@ -480,7 +480,14 @@ void destroy_panel(PanelPlan &p)
 static int resident_waves(int device) { return device_cus(device) * kWgPerCu * kWavesPerWg; }
 
 // spmv_csr_plan: idempotent like the other variants (spmv_csr_plan_set always re-plans: the way to refresh the copied values)
-int plan_panel(spmv_csr &h, hipStream_t s) { return h.plan_panel.ready ? SPMV_OK : plan_panel_with(h, 0, 0, 0, s); }
+// ... unless the caller has announced new values (spmv_csr_values_changed): the copy is then rebuilt as it was planned
+int plan_panel(spmv_csr &h, hipStream_t s)
+{
+    const PanelPlan &p = h.plan_panel;
+    if (!p.ready) return plan_panel_with(h, 0, 0, 0, s);
+    if (p.stamp.gen == h.values_gen) return SPMV_OK;
+    return plan_panel_with(h, p.pw_bits, p.waves_per_launch, p.lds_mode ? 2 : 1, s);
+}
 
 // want_mode: 0 = the rule below, 1 = panels through L2 (k_panel), 2 = panels staged in LDS (k_panel_lds)
 int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, hipStream_t s)
@@ -534,6 +541,7 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, h
     if (p.lds_mode) p.waves_per_launch = device_cus(h.device) * kLdsWaves;   // one 16-wavefront workgroup per CU and round
     if (h.rows == 0) {
         p.ready = true;
+        p.stamp.gen = h.values_gen;
         h.plan_panel = p;
         return SPMV_OK;
     }
@@ -589,6 +597,7 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, h
             if ((rc = check_launch("k_panel_joins"))) return rc;
         }
     }
+    if ((rc = stamp_values(h, s, p.stamp))) return rc;
     SPMV_HIP_TRY(hipStreamSynchronize(s));   // the temporaries are freed on return
     p.d_packed = packed.release();
     p.d_pvals = pvals.release();
@@ -612,6 +621,7 @@ int launch_panel(const spmv_csr &h, const float *x, float *y, hipStream_t s)
         set_error("spmv_csr_run: variant panel is not planned (call spmv_csr_plan first)");
         return SPMV_ERR_NOT_PLANNED;
     }
+    if (int rc = require_fresh_values(h, p.stamp, s, "panel")) return rc;
     if (p.lds_mode) {
         if (p.nblocks == 0) return SPMV_OK;
         const size_t lds = sizeof(float) * (size_t)(2 * kLdsW + kLdsWaves * kRwLds);

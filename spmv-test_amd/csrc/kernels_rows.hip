@@ -14,6 +14,7 @@
 //              role of asp_kernel_v* (src/kernels/asp.cu:6-211: many outputs per block).
 //
 // All three are HBM/gather bound: no LDS, no MFMA (0.25 flop/byte).
+#include <cstdlib>
 #include "spmv_internal.hpp"
 
 namespace spmv {
@@ -391,6 +392,77 @@ int launch_validate(const spmv_csr *h, int32_t *d_bad4, hipStream_t stream)
                                                                    h->d_col_idx, d_bad4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_validate launch", __FILE__, __LINE__);
+    return SPMV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Checksum of vals for the stale-plan guard (SPMV_CHECK_VALUES=1): position-mixed, so a permutation changes it too.
+__global__ __launch_bounds__(256) void k_values_checksum(int64_t nnz, const float *__restrict__ vals,
+                                                         unsigned long long *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long acc = 0ull;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) {
+        unsigned long long v = (unsigned long long)__float_as_uint(vals[k]) + 0x9e3779b97f4a7c15ull * (unsigned long long)(k + 1);
+        v ^= v >> 30; v *= 0xbf58476d1ce4e5b9ull; v ^= v >> 27; v *= 0x94d049bb133111ebull; v ^= v >> 31;
+        acc += v;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(out, acc);
+}
+
+int values_checksum(const spmv_csr &h, hipStream_t s, uint64_t *out)
+{
+    DevPtr<unsigned long long> d;
+    SPMV_HIP_TRY(d.alloc(1));
+    SPMV_HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(unsigned long long), s));
+    if (h.nnz > 0) {
+        int64_t blocks = (h.nnz + 256 * 16 - 1) / (256 * 16);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        k_values_checksum<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(h.nnz, h.d_vals, d.p);
+        if (int rc = check_launch("k_values_checksum")) return rc;
+    }
+    unsigned long long v = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&v, d.p, sizeof v, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    *out = (uint64_t)v;
+    return SPMV_OK;
+}
+
+bool check_values_env()
+{
+    static const bool on = [] { const char *e = getenv("SPMV_CHECK_VALUES"); return e && atoi(e) != 0; }();
+    return on;
+}
+
+int stamp_values(const spmv_csr &h, hipStream_t s, ValuesStamp &st)
+{
+    st.gen = h.values_gen;
+    st.have_sum = false;
+    if (!check_values_env()) return SPMV_OK;
+    if (int rc = values_checksum(h, s, &st.sum)) return rc;
+    st.have_sum = true;
+    return SPMV_OK;
+}
+
+int require_fresh_values(const spmv_csr &h, const ValuesStamp &st, hipStream_t s, const char *variant)
+{
+    if (st.gen != h.values_gen) {
+        set_error("spmv_csr_run(%s): the plan holds a copy of vals taken before spmv_csr_values_changed; re-plan "
+                  "(spmv_csr_plan rebuilds a stale plan, spmv_csr_plan_set always rebuilds)", variant);
+        return SPMV_ERR_STALE_PLAN;
+    }
+    if (st.have_sum && check_values_env()) {
+        uint64_t now = 0;
+        if (int rc = values_checksum(h, s, &now)) return rc;
+        if (now != st.sum) {
+            set_error("spmv_csr_run(%s): SPMV_CHECK_VALUES: vals changed since the plan copied them (checksum %016llx, "
+                      "planned with %016llx) and spmv_csr_values_changed was not called; re-plan", variant,
+                      (unsigned long long)now, (unsigned long long)st.sum);
+            return SPMV_ERR_STALE_PLAN;
+        }
+    }
     return SPMV_OK;
 }
 

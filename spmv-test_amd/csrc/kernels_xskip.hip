@@ -18,7 +18,7 @@
 //
 // Scope: the reference's own regime -- dense-ish matrices.  The plan counts nonzeros per (block, input) in a table
 // of blocks x cols integers, so it refuses matrices where that table would exceed 2^27 entries; and the plain
-// read-add-write needs rows without duplicate columns (checked for sorted rows).  The values are COPIED (re-plan
+// read-add-write needs rows without duplicate columns: rows must be sorted and duplicate-free (both checked).  The values are COPIED (re-plan
 // after changing them), like SPMV_PANEL.
 #include "spmv_internal.hpp"
 
@@ -38,7 +38,9 @@ int check_launch(const char *what)
     return SPMV_OK;
 }
 
-// cnt[b*cols + j] = nonzeros of input j in output block b; dup[0] = 1 when a row holds the same column twice in a row
+// cnt[b*cols + j] = nonzeros of input j in output block b; dup[0] = 1 when a row holds the same column twice in a
+// row, dup[1] = 1 when the columns of a row do not ascend (then a duplicate need not be adjacent: [3, 5, 3] -- two lanes
+// of one segment would read-add-write the same LDS word, so the plan refuses unsorted rows outright)
 __global__ __launch_bounds__(kBlock) void k_xs_count(int64_t rows, int64_t cols, const int32_t *__restrict__ row_ptr,
                                                      const int32_t *__restrict__ col_idx, int32_t *__restrict__ cnt,
                                                      int32_t *__restrict__ dup)
@@ -51,7 +53,11 @@ __global__ __launch_bounds__(kBlock) void k_xs_count(int64_t rows, int64_t cols,
     for (int32_t k = s + lane; k < e; k += kWave) {
         const int32_t j = col_idx[k];
         atomicAdd(&cnt[b * cols + j], 1);
-        if (k + 1 < e && col_idx[k + 1] == j) dup[0] = 1;
+        if (k + 1 < e) {
+            const int32_t nx = col_idx[k + 1];
+            if (nx == j) dup[0] = 1;
+            if (nx < j) dup[1] = 1;
+        }
     }
 }
 
@@ -179,7 +185,7 @@ void destroy_xskip(XskipPlan &p)
 
 int plan_xskip(spmv_csr &h, hipStream_t s)
 {
-    if (h.plan_xskip.ready) return SPMV_OK;
+    if (h.plan_xskip.ready && h.plan_xskip.stamp.gen == h.values_gen) return SPMV_OK;   // (a stale copy is rebuilt)
     destroy_xskip(h.plan_xskip);
     XskipPlan p;
     p.nblocks = (int)((h.rows + kXR - 1) / kXR);
@@ -191,6 +197,7 @@ int plan_xskip(spmv_csr &h, hipStream_t s)
     }
     if (h.rows == 0 || h.nnz == 0) {
         p.ready = true;
+        p.stamp.gen = h.values_gen;
         h.plan_xskip = p;
         return SPMV_OK;
     }
@@ -201,9 +208,9 @@ int plan_xskip(spmv_csr &h, hipStream_t s)
     SPMV_HIP_TRY(flag.alloc((size_t)table));
     SPMV_HIP_TRY(tot_nnz.alloc(1));
     SPMV_HIP_TRY(tot_seg.alloc(1));
-    SPMV_HIP_TRY(dup.alloc(1));
+    SPMV_HIP_TRY(dup.alloc(2));
     SPMV_HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (size_t)table, s));
-    SPMV_HIP_TRY(hipMemsetAsync(dup.p, 0, sizeof(int32_t), s));
+    SPMV_HIP_TRY(hipMemsetAsync(dup.p, 0, 2 * sizeof(int32_t), s));
     const unsigned grows = (unsigned)((h.rows + 3) / 4), gtab = (unsigned)((table + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_xs_count, dim3(grows), dim3(kBlock), 0, s, h.rows, h.cols, h.d_row_ptr, h.d_col_idx, cnt.p, dup.p);
     if ((rc = check_launch("k_xs_count"))) return rc;
@@ -212,12 +219,17 @@ int plan_xskip(spmv_csr &h, hipStream_t s)
     hipLaunchKernelGGL(k_xs_flags, dim3(gtab), dim3(kBlock), 0, s, table, cnt.p, flag.p);
     if ((rc = check_launch("k_xs_flags"))) return rc;
     if ((rc = exclusive_scan_i32(flag.p, table, tot_seg.p, s))) return rc;
-    int32_t nseg = 0, has_dup = 0;
+    int32_t nseg = 0, has_dup[2] = {0, 0};
     SPMV_HIP_TRY(hipMemcpyAsync(&nseg, tot_seg.p, sizeof nseg, hipMemcpyDeviceToHost, s));
-    SPMV_HIP_TRY(hipMemcpyAsync(&has_dup, dup.p, sizeof has_dup, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipMemcpyAsync(has_dup, dup.p, sizeof has_dup, hipMemcpyDeviceToHost, s));
     SPMV_HIP_TRY(hipStreamSynchronize(s));
-    if (has_dup) {
-        set_error("spmv_csr_plan(xskip): a row holds the same column twice; this variant needs duplicate-free rows");
+    if (has_dup[0]) {
+        set_error("spmv_csr_plan(xskip): a row holds the same column twice; this variant needs sorted, duplicate-free rows");
+        return SPMV_ERR_INVALID;
+    }
+    if (has_dup[1]) {
+        set_error("spmv_csr_plan(xskip): the columns of a row do not ascend; this variant needs sorted, duplicate-free rows "
+                  "(a duplicate column in an unsorted row would go unnoticed)");
         return SPMV_ERR_INVALID;
     }
     p.nseg = nseg;
@@ -242,6 +254,7 @@ int plan_xskip(spmv_csr &h, hipStream_t s)
     if (slabs > kXSlabMax) slabs = kXSlabMax;
     if (slabs < 1) slabs = 1;
     p.slabs = slabs;
+    if ((rc = stamp_values(h, s, p.stamp))) return rc;
     if (slabs > 1) SPMV_HIP_TRY(hipMalloc((void **)&p.d_part, sizeof(float) * (size_t)p.nblocks * slabs * kXR));
     SPMV_HIP_TRY(hipStreamSynchronize(s));   // the temporaries are freed on return
     p.d_block_seg = block_seg.release();
@@ -261,6 +274,7 @@ int launch_xskip(const spmv_csr &h, const float *x, float *y, hipStream_t s)
         set_error("spmv_csr_run: variant xskip is not planned (call spmv_csr_plan first)");
         return SPMV_ERR_NOT_PLANNED;
     }
+    if (int rc = require_fresh_values(h, p.stamp, s, "xskip")) return rc;
     if (h.rows == 0) return SPMV_OK;
     if (h.nnz == 0) {
         SPMV_HIP_TRY(hipMemsetAsync(y, 0, sizeof(float) * (size_t)h.rows, s));

@@ -88,6 +88,14 @@ struct ChunkPlan {
     int staged_full = 0;       // TILED: chunks staged completely (any number of passes)
 };
 
+// Plans that COPY the values (PANEL, XSKIP) remember which state of vals they copied: the handle's generation counter
+// (spmv_csr_values_changed bumps it) and, under SPMV_CHECK_VALUES=1, a checksum of the array itself.
+struct ValuesStamp {
+    uint64_t gen = 0;
+    uint64_t sum = 0;
+    bool have_sum = false;
+};
+
 // SPMV_PANEL (kernels_panel.hip): row blocks of at most 8192 rows and equal nonzero counts, each block's nonzeros stably sorted by column panel.
 struct PanelPlan {
     bool ready = false;
@@ -100,6 +108,7 @@ struct PanelPlan {
     float *d_pvals = nullptr;      // [nnz + slack] values in the same order (a COPY: re-plan after changing vals)
     int32_t *d_tile_ptr = nullptr; // [nblocks * (npanels + 1)]
     int32_t *d_brow = nullptr;     // [nblocks + 1] first row of every block
+    ValuesStamp stamp;             // which state of vals d_pvals is a copy of
 };
 
 // SPMV_XSKIP (kernels_xskip.hip): the matrix in input-major segments per block of 1024 outputs
@@ -112,6 +121,7 @@ struct XskipPlan {
     uint16_t *d_erow = nullptr;       // [nnz] output - 1024 * block
     float *d_evals = nullptr;         // [nnz] values in segment order (a COPY: re-plan after changing vals)
     float *d_part = nullptr;          // [nblocks * slabs * 1024] slab partials (slabs > 1)
+    ValuesStamp stamp;                // which state of vals d_evals is a copy of
 };
 
 }  // namespace spmv
@@ -135,6 +145,7 @@ struct spmv_csr {
     spmv::PanelPlan plan_panel;    // SPMV_PANEL
     spmv::XskipPlan plan_xskip;    // SPMV_XSKIP
     int auto_variant = -1;         // SPMV_AUTO: the variant its plan chose (-1 = not planned)
+    uint64_t values_gen = 0;       // bumped by spmv_csr_values_changed: plans that copied vals before that are stale
 };
 
 namespace spmv {
@@ -159,6 +170,7 @@ int plan_tiled_with(spmv_csr &h, int block, int maxpass, bool col16, hipStream_t
 int plan_adaptive_with(spmv_csr &h, int block, hipStream_t s);
 int plan_panel_with(spmv_csr &h, int pw_bits, int waves_per_launch, int mode, hipStream_t s);   // 0 = library default
 void destroy_plans(spmv_csr &h);
+void drop_tiled_plan(spmv_csr &h);   // SPMV_AUTO resolved to another variant: the TILED plan it looked at is released
 
 int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out);
 int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s);
@@ -169,6 +181,12 @@ int dense_gemv_ws(int M, int N, const float *d_A, const float *d_x, float *d_y, 
 // kernels_rows.hip: structural check of a CSR (bad[0] first row with row_ptr[r] > row_ptr[r+1] or outside [0,nnz],
 // bad[1] first element with a column outside [0,cols), bad[2]/bad[3] row_ptr[0] / row_ptr[rows] when wrong)
 int launch_validate(const spmv_csr *h, int32_t *d_bad4, hipStream_t stream);
+// order-sensitive 64-bit checksum of vals (a device pass + a host wait: debug aid behind SPMV_CHECK_VALUES=1)
+int values_checksum(const spmv_csr &h, hipStream_t s, uint64_t *out);
+bool check_values_env();   // SPMV_CHECK_VALUES=1 (read once)
+// stamp a plan that has just copied vals / refuse to run one whose copy is out of date (SPMV_ERR_STALE_PLAN)
+int stamp_values(const spmv_csr &h, hipStream_t s, ValuesStamp &st);
+int require_fresh_values(const spmv_csr &h, const ValuesStamp &st, hipStream_t s, const char *variant);
 // in-place exclusive scan of n int32 (one 1024-thread workgroup); the total goes to *d_total
 int exclusive_scan_i32(int32_t *d_data, int64_t n, int32_t *d_total, hipStream_t s);
 
