@@ -36,6 +36,47 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+COPY_CEILING_GBS = 6290.0  # same guide: what a float4 copy reaches (79 % of spec) -- no kernel MOVES bytes faster than this
+L2_LINE_PEAK_G = 270.0     # profiles/r03_gather_lines_ubench.jsonl: 128-byte line requests per second the L2s serve (G/s)
+
+
+def touched_x_bytes(torch, d_ci, cols):
+    """4 bytes x the DISTINCT columns the matrix references (the CSR-algorithmic count charges all of x: a shard of
+    config 5 with banded columns touches 64 MiB of its 512 MiB)."""
+    mask = torch.zeros(cols, dtype=torch.bool, device=d_ci.device)
+    step = 1 << 25
+    for k in range(0, d_ci.numel(), step):
+        mask[d_ci[k:k + step].long()] = True
+    return 4 * int(mask.sum().item())
+
+
+def honest_fields(be, ms, nnz, rows, touched_x, plan_text, traffic_entry):
+    """What the line says about a kernel time besides 'algorithmic bytes / time / 8 TB/s' (VERDICT round 2, item 2)."""
+    out = {}
+    touched = 8 * nnz + 4 * (rows + 1) + 4 * rows + touched_x
+    out["bytes_touched"] = touched                    # x counted as the distinct columns referenced
+    out["frac_of_peak_touched"] = round(touched / ms / 1e6 / HBM_PEAK_GBS, 4)
+    if be / ms / 1e6 > COPY_CEILING_GBS:
+        out["exceeds_copy_ceiling"] = (f"algorithmic bytes / time = {be / ms / 1e6:.0f} GB/s is above the {COPY_CEILING_GBS:.0f} GB/s "
+                                       "a pure copy reaches: the kernel does not move that many bytes (x columns never "
+                                       "referenced, 16-bit column copies) -- read frac_of_peak_touched / frac_hbm_counters")
+    if traffic_entry is not None:
+        out["hbm_bytes_counters"] = traffic_entry["hbm_bytes_per_launch"]
+        out["frac_hbm_counters"] = round(traffic_entry["hbm_bytes_per_launch"] / ms / 1e6 / HBM_PEAK_GBS, 4)
+        out["counters_from"] = "profiles/" + traffic_entry.get("profile", "?")
+    # the panel family is bound by L2 line requests, not by HBM bytes: a second roofline with that ceiling
+    if "auto -> panel" in plan_text or plan_text.startswith(("panel_columns", "sorted_blocks")):
+        if "lines_per_nonzero=" in plan_text:
+            lines = float(plan_text.split("lines_per_nonzero=")[1].split()[0]) * nnz
+            what = "lines_per_nonzero of the plan x nonzeros (distinct 128-byte lines of x per block, each requested about once)"
+        else:
+            lines = float(nnz)
+            what = "one line request per nonzero (rows ascend inside a tile: the lanes of an instruction hold different lines)"
+        out["roofline_l2_gather"] = {"bound": "l2_gather", "achieved": round(lines / ms / 1e6, 1), "peak": L2_LINE_PEAK_G,
+                                     "unit": "G line requests/s", "frac": round(lines / ms / 1e6 / L2_LINE_PEAK_G, 4),
+                                     "requests": what,
+                                     "peak_from": "tools/ubench_gather_lines.hip: 64 lanes on 64 distinct L2-resident lines"}
+    return out
 
 
 def parse():
@@ -360,8 +401,25 @@ def main():
         del A, d_rp, d_ci, d_va, d_x, d_y, handles, keep
         torch.cuda.empty_cache()
         extras = []
-        todo = [("c4", 0), ("c4", 2048), ("c4", 65536), ("c4", 200000), ("c2", 0), ("c2", 8192), ("c3", 0), ("c3", 8192),
-                ("c5", 8192), ("c5", 0)]
+        try:
+            traffic_all = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+        except Exception:
+            traffic_all = {}
+        # rocSPARSE beside every workload (the reference's vendor slot, cublas.cu:33, is a comparison there too); the
+        # library is part of the ROCm image -- when it does not load the fields are simply absent
+        rocs, vendor = None, None
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("vendor_compare", ROOT / "tools" / "vendor_compare.py")
+            vendor = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(vendor)
+            rocs = vendor.RocSparse()
+            import ctypes
+            rocs._ok(rocs.L.rocsparse_set_stream(rocs.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "set_stream")
+        except Exception:
+            rocs = None
+        todo = [("c4", 0), ("c4", 2048), ("c4", 65536), ("c4", 200000), ("c4", 1000000), ("c2", 0), ("c2", 8192), ("c3", 0),
+                ("c3", 8192), ("c5", 8192), ("c5", 0)]
         for cname, band in todo:
             if cname == args.config and band == args.band:
                 continue
@@ -386,30 +444,55 @@ def main():
             capi.synth_x(we.seed, 0, we.cols, e_x)
             Ae = capi.CsrMatrix.from_device(n_loc, we.cols, e_rp, e_ci, e_va)
             be = W.algorithmic_bytes(n_loc, we.cols, nnz_e)
-            best, auto = None, None
-            for vn in ("auto", "adaptive", "tiled", "vector") + (("panel",) if band == 0 else ()):
-                v = capi.VARIANTS[vn]
+            # every variant timed the same way: warm launches, then the best of three groups of 20; SPMV_AUTO last, so
+            # that it meets clocks and caches in the state its resolved variant met (round 2: "auto" ran first and read
+            # up to 3.5 % slower than the variant it resolves to)
+            def timed(v, iters=20, groups=3):
                 Ae.plan(v)
-                Ae.time(v, e_x, e_y, 3)
-                ms = min(Ae.time(v, e_x, e_y, 20) for _ in range(2))
+                Ae.time(v, e_x, e_y, 10)
+                return min(Ae.time(v, e_x, e_y, iters) for _ in range(groups))
+            best, auto = None, None
+            times = {}
+            for vn in ("adaptive", "tiled", "vector") + (("panel",) if band == 0 else ()) + ("auto",):
+                ms = timed(capi.VARIANTS[vn])
+                times[vn] = ms
                 if vn == "auto":
-                    auto = (Ae.plan_describe(v).split(":")[0], ms)
+                    auto = (Ae.plan_describe(capi.VARIANTS[vn]), ms)
                 if best is None or ms < best[1]:
                     best = (vn, ms)
+            auto_plan = auto[0]
+            resolved = auto_plan.split("auto -> ")[1].split(":")[0] if "auto -> " in auto_plan else "auto"
             # the kernel BASELINE.json's config string names for this config, timed beside the library's choice
             named = {"c2": ("scalar",), "c3": ("wave", "wave_pipe")}.get(cname, ())
             named_out = {}
             for vn in named:
-                v = capi.VARIANTS[vn]
-                Ae.plan(v)
-                Ae.time(v, e_x, e_y, 2)
-                ms = min(Ae.time(v, e_x, e_y, 10) for _ in range(2))
+                ms = timed(capi.VARIANTS[vn], iters=10, groups=2)
                 named_out[vn] = {"kernel_ms": round(ms, 5), "frac_of_peak": round(be / ms / 1e6 / HBM_PEAK_GBS, 4)}
-            extras.append({"workload": label, "auto": auto[0], "auto_kernel_ms": round(auto[1], 5),
-                           "auto_frac_of_peak": round(be / auto[1] / 1e6 / HBM_PEAK_GBS, 4),
-                           "best_variant": best[0], "best_kernel_ms": round(best[1], 5),
-                           "best_frac_of_peak": round(be / best[1] / 1e6 / HBM_PEAK_GBS, 4),
-                           "algorithmic_bytes": be, **({"config_named_kernel": named_out} if named_out else {})})
+            tx = touched_x_bytes(torch, e_ci, we.cols)
+            tkey = f"{resolved}:{cname}:band{band}"
+            tent = traffic_all.get(tkey)
+            if tent is not None and tent.get("plan", "").split(": ", 1)[-1] != auto_plan.split(": ", 1)[-1]:
+                tent = None                                      # taken with another plan: not replayed
+            entry = {"workload": label, "auto": auto_plan.split(":")[0], "auto_plan": auto_plan,
+                     "auto_kernel_ms": round(auto[1], 5),
+                     "auto_frac_of_peak": round(be / auto[1] / 1e6 / HBM_PEAK_GBS, 4),
+                     "best_variant": best[0], "best_kernel_ms": round(best[1], 5),
+                     "best_frac_of_peak": round(be / best[1] / 1e6 / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes": be, **honest_fields(be, auto[1], nnz_e, n_loc, tx, auto_plan, tent),
+                     **({"config_named_kernel": named_out} if named_out else {})}
+            if resolved in times:
+                entry["resolved_variant_kernel_ms"] = round(times[resolved], 5)   # the same plan timed under its own name
+            if rocs is not None:
+                try:
+                    rt = vendor.rocsparse_times(rocs, n_loc, we.cols, nnz_e, e_rp, e_ci, e_va, e_x, e_y, iters=10)
+                    if rt:
+                        ba = min(rt, key=lambda a: rt[a][0])
+                        entry["rocsparse_best_ms"] = round(rt[ba][0], 5)
+                        entry["rocsparse_best_algorithm"] = ba
+                        entry["speedup_vs_rocsparse_best"] = round(rt[ba][0] / auto[1], 2)
+                except Exception as ex:                      # a comparison, never a reason to lose the line
+                    entry["rocsparse_error"] = str(ex)[:120]
+            extras.append(entry)
             Ae.close()
             del e_rp, e_ci, e_va, e_x, e_y
             torch.cuda.empty_cache()

@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" entry points of include/spmv_hip.h.
 #include <cstdarg>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include "spmv_internal.hpp"
@@ -284,24 +285,60 @@ int spmv_csr_destroy(spmv_csr_t *h)
     return rc;
 }
 
-// SPMV_AUTO: plan TILED (cheap: a few passes over col_idx, no trial launches) and look at what it could stage.
-// A plan that stages less than half of the chunks gathers most of x through L2/fabric -- one request per nonzero --
-// and when x fills one XCD's 4 MiB L2 or more that is where the panel sweep is faster (1.2x at config 2's 4 MiB, 3-4x at
-// 64 MiB: DESIGN.md section 4); below that size x sits in every L2 anyway and the row-major kernel keeps its lead.
+// SPMV_AUTO.  TILED's plan is made first (cheap: a few passes over col_idx, no trial launches) and priced (model_cost,
+// in units of "a chunk that streams 8 bytes per nonzero with cache-resident gathers").
+//   1. It stages (nearly) everything in one or two passes (model_cost <= 1.20: bands up to ~60 000 columns at config 4): TILED.
+//   2. Otherwise the sorted-blocks layout of SPMV_PANEL (kernels_colsort.hip) is tried where a look at the matrix says it can
+//      work -- short rows (at most a tenth of the nonzeros in rows of more than 256), blocks of 4096 rows whose window of
+//      x fits an L2 -- and taken when its own model prices it below TILED (wide bands: 65 536 columns and beyond; uniform
+//      columns over a few MiB of x: config 2).
+//   3. Otherwise, when TILED could stage or sort less than half of the chunks -- it gathers most of x through L2/fabric,
+//      one request per nonzero -- and x fills one XCD's 4 MiB L2 or more, the panel sweep (1.2x at config 2's 4 MiB, 3-4x at
+//      64 MiB: DESIGN.md section 4); below that size x sits in every L2 anyway and the row-major kernel keeps its lead.
 static int plan_auto(spmv_csr &h, hipStream_t s)
 {
+    if (h.auto_variant == SPMV_PANEL) return refresh_panel(h, h.plan_auto_panel, s);   // idempotent, except that a stale copy of vals is rebuilt
     if (h.auto_variant >= 0) return SPMV_OK;
+    h.auto_made_tiled = h.plan_tiled.block == 0;
     int rc = plan_adaptive(h, true, s);
     if (rc) return rc;
+    // a TILED plan the caller made stays; one made here for a look is released when another variant is chosen (up to
+    // 6 bytes per nonzero of column copies nobody would read)
+    auto release_tiled = [&]() { if (h.auto_made_tiled) drop_tiled_plan(h); h.auto_made_tiled = false; };
     const ChunkPlan &p = h.plan_tiled;
+    const double cost_tiled = p.model_cost;
     const bool little_staged = p.nchunks > 0 && 2 * ((int64_t)p.staged_full + p.nsorted) < p.nchunks &&
                                2 * (int64_t)p.nblk_chunks < p.nchunks;
     const bool x_beyond_l2 = h.cols * (int64_t)sizeof(float) >= (4ll << 20);   // an L2 also holds the stream passing through
+    // (a workgroup per 4096 rows, one or two per CU: fewer blocks than three quarters of the CUs leave the chip idle)
+    bool try_sorted = p.nchunks > 0 && cost_tiled > 1.20 && 2 * (int64_t)p.nblk_chunks < p.nchunks &&
+                      h.rows >= 4096ll * (3 * device_cus(h.device) / 4);
+    if (const char *e = getenv("SPMV_AUTO_SORTED_BLOCKS")) try_sorted = try_sorted && atoi(e) != 0;   // 0: never (A/B runs)
+    if (try_sorted) {
+        double long_frac = 0.0, wide_frac = 0.0, lines_est = 0.0;
+        if ((rc = colsort_probe(h, s, &long_frac, &wide_frac, &lines_est))) return rc;
+        // (the estimate of the lines per nonzero prices the layout before it is built: 5 % slack for what it cannot see)
+        if (long_frac <= 0.10 && wide_frac <= 0.10 && 0.95 * colsort_cost(4096, lines_est, long_frac) < cost_tiled) {
+            rc = build_panel(h, h.plan_auto_panel, 0, 0, 3, s);
+            if (rc == SPMV_OK) {
+                const PanelPlan &pp = h.plan_auto_panel;
+                const bool fits = (double)pp.tail <= 0.10 * (double)h.nnz && 10 * pp.wide_blocks <= pp.nblocks;
+                if (fits && colsort_model_cost(pp, h.nnz) < 0.98 * cost_tiled) {   // (a tie goes to TILED: it reads vals live)
+                    h.auto_variant = SPMV_PANEL;
+                    release_tiled();
+                    return SPMV_OK;
+                }
+                destroy_panel(h.plan_auto_panel);
+            } else if (rc != SPMV_ERR_INVALID) {
+                return rc;   // INVALID: outside the layout's limits -> on with the other candidates
+            }
+        }
+    }
     if (little_staged && x_beyond_l2) {
-        rc = plan_panel(h, s);
+        rc = build_panel(h, h.plan_auto_panel, 0, 0, 1, s);
         if (rc == SPMV_OK) {
             h.auto_variant = SPMV_PANEL;
-            drop_tiled_plan(h);   // up to 6 bytes per nonzero of column copies nobody will read (spmv_csr_plan(TILED) rebuilds it)
+            release_tiled();
             return SPMV_OK;
         }
         if (rc != SPMV_ERR_INVALID) return rc;   // INVALID: outside the panel layout's limits -> stay with TILED
@@ -345,6 +382,7 @@ int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void 
     hipStream_t s = (hipStream_t)stream;
     if (variant == SPMV_AUTO) {
         if (h->auto_variant < 0) { set_error("SPMV_AUTO used before spmv_csr_plan"); return SPMV_ERR_NOT_PLANNED; }
+        if (h->auto_variant == SPMV_PANEL) return launch_panel_plan(*h, h->plan_auto_panel, d_x, d_y, s);
         variant = h->auto_variant;
     }
     switch (variant) {
@@ -373,10 +411,12 @@ int spmv_csr_plan_get(const spmv_csr_t *h, int variant, int32_t params[8])
 {
     if (!h || !params) { set_error("spmv_csr_plan_get: null argument"); return SPMV_ERR_INVALID; }
     for (int i = 0; i < 8; ++i) params[i] = 0;
+    const bool is_auto = variant == SPMV_AUTO;
     if (variant == SPMV_AUTO) {
         if (h->auto_variant < 0) { set_error("spmv_csr_plan_get: SPMV_AUTO is not planned"); return SPMV_ERR_NOT_PLANNED; }
         variant = h->auto_variant;
     }
+    const PanelPlan &panel = is_auto ? h->plan_auto_panel : h->plan_panel;
     params[0] = variant;
     switch (variant) {
         case SPMV_SCALAR: case SPMV_WAVE: case SPMV_WAVE_PIPE: return SPMV_OK;
@@ -393,9 +433,10 @@ int spmv_csr_plan_get(const spmv_csr_t *h, int variant, int32_t params[8])
             params[1] = h->plan_xskip.slabs;
             return SPMV_OK;
         case SPMV_PANEL:
-            if (!h->plan_panel.ready) { set_error("spmv_csr_plan_get: panel is not planned"); return SPMV_ERR_NOT_PLANNED; }
-            params[4] = h->plan_panel.pw_bits; params[5] = h->plan_panel.waves_per_launch;
-            params[6] = h->plan_panel.lds_mode ? 2 : 1;
+            if (!panel.ready) { set_error("spmv_csr_plan_get: panel is not planned"); return SPMV_ERR_NOT_PLANNED; }
+            params[4] = panel.pw_bits; params[5] = panel.waves_per_launch;
+            params[6] = panel.sorted_mode ? 3 : (panel.lds_mode ? 2 : 1);
+            if (panel.sorted_mode) { params[4] = panel.sb_rows; params[5] = panel.sb_waves; }
             return SPMV_OK;
         default: set_error("spmv_csr_plan_get: unknown variant %d", variant); return SPMV_ERR_VARIANT;
     }
@@ -429,7 +470,7 @@ int spmv_csr_plan_set(spmv_csr_t *h, int variant, const int32_t params[8], void 
         }
         case SPMV_ADAPTIVE: rc = plan_adaptive_with(*h, params[1], s); break;
         case SPMV_TILED: rc = plan_tiled_with(*h, params[1], params[2], params[3] != 0, s); break;
-        case SPMV_PANEL: rc = plan_panel_with(*h, params[4], params[5], params[6], s); break;
+        case SPMV_PANEL: rc = build_panel(*h, variant == SPMV_AUTO ? h->plan_auto_panel : h->plan_panel, params[4], params[5], params[6], s); break;
         case SPMV_XSKIP: destroy_xskip(h->plan_xskip); rc = plan_xskip(*h, s); break;   // always rebuilt: the values are a copy
         default: set_error("spmv_csr_plan_set: unknown variant %d", target); return SPMV_ERR_VARIANT;
     }
@@ -447,6 +488,7 @@ int spmv_csr_plan_like(spmv_csr_t *dst, const spmv_csr_t *src, int variant, void
 int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
 {
     if (!h) return 0;
+    const PanelPlan &panel = variant == SPMV_AUTO ? h->plan_auto_panel : h->plan_panel;
     if (variant == SPMV_AUTO) variant = h->auto_variant;
     switch (variant) {
         case SPMV_ADAPTIVE:  // chunk_lb read + carry written and re-read
@@ -460,8 +502,10 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
         case SPMV_XSKIP:     // segment list + slab partials; erow16/evals (6 B per nonzero) REPLACE col_idx/vals (8 B)
             return (int64_t)h->plan_xskip.nseg * 8 + ((int64_t)h->plan_xskip.nblocks + 1) * 4 +
                    (h->plan_xskip.slabs > 1 ? (int64_t)h->plan_xskip.nblocks * h->plan_xskip.slabs * 1024 * 8 : 0);
-        case SPMV_PANEL:     // tile_ptr; packed/pvals REPLACE col_idx/vals byte for byte
-            return (int64_t)h->plan_panel.nblocks * (h->plan_panel.npanels + 1) * 4 + ((int64_t)h->plan_panel.nblocks + 1) * 4;
+        case SPMV_PANEL:     // tile_ptr; packed/pvals REPLACE col_idx/vals byte for byte (sorted blocks: + the empty slots)
+            if (panel.sorted_mode)   // unit bases, block tables, the rows of the tail units, the empty slots of the units in use
+                return panel.units * 4 + (int64_t)panel.nblocks * 20 + panel.tail_units * 512;
+            return (int64_t)panel.nblocks * (panel.npanels + 1) * 4 + ((int64_t)panel.nblocks + 1) * 4;
         default: return 0;
     }
 }
@@ -469,18 +513,28 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
 int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
 {
     if (!h || !buf || n <= 0) { set_error("spmv_csr_plan_describe: bad argument"); return SPMV_ERR_INVALID; }
+    const PanelPlan *panel = &h->plan_panel;
     if (variant == SPMV_AUTO) {   // "auto -> <variant>: <that variant's plan>"
         if (h->auto_variant < 0) { snprintf(buf, (size_t)n, "not planned"); return SPMV_OK; }
         const int w = snprintf(buf, (size_t)n, "auto -> %s: ", spmv_variant_name(h->auto_variant));
         if (w < 0 || w >= n) return SPMV_OK;
-        return spmv_csr_plan_describe(h, h->auto_variant, buf + w, n - w);
+        if (h->auto_variant != SPMV_PANEL) return spmv_csr_plan_describe(h, h->auto_variant, buf + w, n - w);
+        panel = &h->plan_auto_panel;
+        variant = SPMV_PANEL;
+        buf += w;
+        n -= w;
     }
     const ChunkPlan *p = variant == SPMV_ADAPTIVE ? &h->plan_adaptive : (variant == SPMV_TILED ? &h->plan_tiled : nullptr);
     if (variant == SPMV_VECTOR) snprintf(buf, (size_t)n, "lanes_per_row=%d", h->vector_width);
-    else if (variant == SPMV_PANEL && h->plan_panel.ready)
+    else if (variant == SPMV_PANEL && panel->ready && panel->sorted_mode)
+        snprintf(buf, (size_t)n, "sorted_blocks=%d rows_per_block=%d wavefronts=%d lines_per_nonzero=%.3f tail_nonzeros=%lld wide_blocks=%lld model_cost=%.3f",
+                 panel->nblocks, panel->sb_rows, panel->sb_waves,
+                 h->nnz ? (double)panel->lines / (double)h->nnz : 0.0, (long long)panel->tail,
+                 (long long)panel->wide_blocks, colsort_model_cost(*panel, h->nnz));
+    else if (variant == SPMV_PANEL && panel->ready)
         snprintf(buf, (size_t)n, "panel_columns=%d panels=%d row_blocks=%d waves_per_launch=%d launches=%d x_panels_in=%s",
-                 1 << h->plan_panel.pw_bits, h->plan_panel.npanels, h->plan_panel.nblocks,
-                 h->plan_panel.waves_per_launch, panel_launches(h->plan_panel), h->plan_panel.lds_mode ? "LDS" : "L2");
+                 1 << panel->pw_bits, panel->npanels, panel->nblocks,
+                 panel->waves_per_launch, panel_launches(*panel), panel->lds_mode ? "LDS" : "L2");
     else if (variant == SPMV_XSKIP && h->plan_xskip.ready)
         snprintf(buf, (size_t)n, "output_blocks=%d segments=%d slabs_per_block=%d", h->plan_xskip.nblocks, h->plan_xskip.nseg,
                  h->plan_xskip.slabs);

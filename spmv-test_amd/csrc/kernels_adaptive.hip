@@ -1545,6 +1545,7 @@ void destroy_plans(spmv_csr &h)
     free_plan(h.plan_adaptive);
     free_plan(h.plan_tiled);
     destroy_panel(h.plan_panel);
+    destroy_panel(h.plan_auto_panel);
     destroy_xskip(h.plan_xskip);
 }
 

@@ -29,6 +29,7 @@
 // sums are touched by that wave alone, in instruction order.
 // The values are COPIED at plan time (the other variants read the live vals array): re-plan after changing them.
 #include <climits>
+#include <cstdlib>
 #include "spmv_internal.hpp"
 
 namespace spmv {
@@ -467,8 +468,41 @@ int check_launch(const char *what)
 
 }  // namespace
 
+// Row blocks of equal NONZERO counts (nb0 cuts of row_ptr), any cut of more than `cap` rows split evenly:
+// brow[0..nblocks] = first row of every block.  Shared with kernels_colsort.hip.
+int panel_row_blocks(const spmv_csr &h, int64_t nb0, int cap, hipStream_t s, DevPtr<int32_t> &brow, int32_t *nblocks_out)
+{
+    DevPtr<int32_t> cut, nsub, total;
+    SPMV_HIP_TRY(cut.alloc((size_t)nb0 + 1));
+    SPMV_HIP_TRY(nsub.alloc((size_t)nb0));
+    SPMV_HIP_TRY(total.alloc(1));
+    const unsigned gb = (unsigned)((nb0 + 1 + 255) / 256);
+    k_panel_cuts<<<dim3(gb), dim3(256), 0, s>>>(h.rows, h.nnz, (int)nb0, h.d_row_ptr, cut.p);
+    int rc = check_launch("k_panel_cuts");
+    if (rc) return rc;
+    k_panel_nsub<<<dim3(gb), dim3(256), 0, s>>>((int)nb0, cap, cut.p, nsub.p);
+    if ((rc = check_launch("k_panel_nsub"))) return rc;
+    if ((rc = exclusive_scan_i32(nsub.p, nb0, total.p, s))) return rc;
+    int32_t nblocks = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&nblocks, total.p, sizeof nblocks, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    SPMV_HIP_TRY(brow.alloc((size_t)nblocks + 1));
+    k_panel_brow<<<dim3(gb), dim3(256), 0, s>>>(h.rows, (int)nb0, cap, cut.p, nsub.p, total.p, brow.p);
+    if ((rc = check_launch("k_panel_brow"))) return rc;
+    SPMV_HIP_TRY(hipStreamSynchronize(s));   // the temporaries are freed on return
+    *nblocks_out = nblocks;
+    return SPMV_OK;
+}
+
+int panel_rowloc(const spmv_csr &h, const int32_t *d_brow, int nblocks, uint16_t *d_rowloc, hipStream_t s)
+{
+    k_panel_rowloc<<<dim3((unsigned)nblocks), dim3(256), 0, s>>>(d_brow, h.d_row_ptr, d_rowloc);
+    return check_launch("k_panel_rowloc");
+}
+
 void destroy_panel(PanelPlan &p)
 {
+    destroy_colsort(p);
     if (p.d_packed) (void)hipFree(p.d_packed);
     if (p.d_pvals) (void)hipFree(p.d_pvals);
     if (p.d_tile_ptr) (void)hipFree(p.d_tile_ptr);
@@ -481,19 +515,43 @@ static int resident_waves(int device) { return device_cus(device) * kWgPerCu * k
 
 // spmv_csr_plan: idempotent like the other variants (spmv_csr_plan_set always re-plans: the way to refresh the copied values)
 // ... unless the caller has announced new values (spmv_csr_values_changed): the copy is then rebuilt as it was planned
-int plan_panel(spmv_csr &h, hipStream_t s)
+int plan_panel(spmv_csr &h, hipStream_t s) { return refresh_panel(h, h.plan_panel, s); }
+
+// `dst` is one of the handle's two panel plans: plan_panel (SPMV_PANEL) or plan_auto_panel (what SPMV_AUTO chose: its
+// own, so that planning AUTO never disturbs a PANEL plan the caller made, and the other way round)
+int refresh_panel(spmv_csr &h, PanelPlan &dst, hipStream_t s)
 {
-    const PanelPlan &p = h.plan_panel;
-    if (!p.ready) return plan_panel_with(h, 0, 0, 0, s);
-    if (p.stamp.gen == h.values_gen) return SPMV_OK;
-    return plan_panel_with(h, p.pw_bits, p.waves_per_launch, p.lds_mode ? 2 : 1, s);
+    if (!dst.ready) return build_panel(h, dst, 0, 0, 0, s);
+    if (dst.stamp.gen == h.values_gen) return SPMV_OK;
+    if (dst.sorted_mode) return build_panel(h, dst, dst.sb_rows, dst.sb_waves, 3, s);
+    return build_panel(h, dst, dst.pw_bits, dst.waves_per_launch, dst.lds_mode ? 2 : 1, s);
 }
 
-// want_mode: 0 = the rule below, 1 = panels through L2 (k_panel), 2 = panels staged in LDS (k_panel_lds)
 int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, hipStream_t s)
 {
-    destroy_panel(h.plan_panel);
+    return build_panel(h, h.plan_panel, want_bits, want_waves, want_mode, s);
+}
+
+// want_mode: 0 = the rule below, 1 = panels through L2 (k_panel), 2 = panels staged in LDS (k_panel_lds),
+//            3 = sorted blocks (kernels_colsort.hip; SPMV_PANEL_SORTED=1 makes it the rule's answer)
+int build_panel(spmv_csr &h, PanelPlan &dst, int want_bits, int want_waves, int want_mode, hipStream_t s)
+{
+    destroy_panel(dst);
     PanelPlan p;
+    {
+        bool sorted = false;
+        if (const char *e = getenv("SPMV_PANEL_SORTED")) sorted = atoi(e) != 0;
+        if (want_mode == 3 || (want_mode == 0 && sorted)) {
+            if (h.nnz > (int64_t)INT_MAX / 17 * 16 - 4096) {
+                set_error("spmv_csr_plan(panel, sorted blocks): nnz %lld too close to 2^31 for one handle", (long long)h.nnz);
+                return SPMV_ERR_INVALID;
+            }
+            const int rc = plan_colsort(h, p, want_mode == 3 ? want_bits : 0, want_mode == 3 ? want_waves : 0, s);
+            if (rc) { destroy_panel(p); return rc; }
+            dst = p;
+            return SPMV_OK;
+        }
+    }
     {
         // LDS mode (k_panel_lds) is never chosen by the library: it was built to test whether staging the panels of a
         // SMALL x in LDS beats gathering them through L2 and measured slower where it had
@@ -542,7 +600,7 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, h
     if (h.rows == 0) {
         p.ready = true;
         p.stamp.gen = h.values_gen;
-        h.plan_panel = p;
+        dst = p;
         return SPMV_OK;
     }
     const int64_t launches0 =
@@ -551,24 +609,9 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, h
     const int cap = p.lds_mode ? kRwLds : kRw;
     if (p.lds_mode) nb0 = (h.rows + kRwLdsTarget - 1) / kRwLdsTarget;
     if (nb0 > h.rows) nb0 = h.rows;
-    DevPtr<int32_t> cut, nsub, total, brow;
-    SPMV_HIP_TRY(cut.alloc((size_t)nb0 + 1));
-    SPMV_HIP_TRY(nsub.alloc((size_t)nb0));
-    SPMV_HIP_TRY(total.alloc(1));
-    const unsigned gb = (unsigned)((nb0 + 1 + 255) / 256);
-    k_panel_cuts<<<dim3(gb), dim3(256), 0, s>>>(h.rows, h.nnz, (int)nb0, h.d_row_ptr, cut.p);
-    int rc = check_launch("k_panel_cuts");
+    DevPtr<int32_t> brow;
+    int rc = panel_row_blocks(h, nb0, cap, s, brow, &p.nblocks);
     if (rc) return rc;
-    k_panel_nsub<<<dim3(gb), dim3(256), 0, s>>>((int)nb0, cap, cut.p, nsub.p);
-    if ((rc = check_launch("k_panel_nsub"))) return rc;
-    if ((rc = exclusive_scan_i32(nsub.p, nb0, total.p, s))) return rc;
-    int32_t nblocks = 0;
-    SPMV_HIP_TRY(hipMemcpyAsync(&nblocks, total.p, sizeof nblocks, hipMemcpyDeviceToHost, s));
-    SPMV_HIP_TRY(hipStreamSynchronize(s));
-    p.nblocks = nblocks;
-    SPMV_HIP_TRY(brow.alloc((size_t)p.nblocks + 1));
-    k_panel_brow<<<dim3(gb), dim3(256), 0, s>>>(h.rows, (int)nb0, cap, cut.p, nsub.p, total.p, brow.p);
-    if ((rc = check_launch("k_panel_brow"))) return rc;
 
     DevPtr<uint32_t> packed;
     DevPtr<float> pvals;
@@ -604,24 +647,26 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, h
     p.d_tile_ptr = tiles.release();
     p.d_brow = brow.release();
     p.ready = true;
-    h.plan_panel = p;
+    dst = p;
     return SPMV_OK;
 }
 
 int panel_launches(const PanelPlan &p)
 {
-    if (p.lds_mode) return p.nblocks ? 1 : 0;
+    if (p.lds_mode || p.sorted_mode) return p.nblocks ? 1 : 0;
     return p.nblocks && p.waves_per_launch ? (p.nblocks + p.waves_per_launch - 1) / p.waves_per_launch : 0;
 }
 
-int launch_panel(const spmv_csr &h, const float *x, float *y, hipStream_t s)
+int launch_panel(const spmv_csr &h, const float *x, float *y, hipStream_t s) { return launch_panel_plan(h, h.plan_panel, x, y, s); }
+
+int launch_panel_plan(const spmv_csr &h, const PanelPlan &p, const float *x, float *y, hipStream_t s)
 {
-    const PanelPlan &p = h.plan_panel;
     if (!p.ready) {
         set_error("spmv_csr_run: variant panel is not planned (call spmv_csr_plan first)");
         return SPMV_ERR_NOT_PLANNED;
     }
     if (int rc = require_fresh_values(h, p.stamp, s, "panel")) return rc;
+    if (p.sorted_mode) return launch_colsort(h, p, x, y, s);
     if (p.lds_mode) {
         if (p.nblocks == 0) return SPMV_OK;
         const size_t lds = sizeof(float) * (size_t)(2 * kLdsW + kLdsWaves * kRwLds);

@@ -109,6 +109,21 @@ struct PanelPlan {
     int32_t *d_tile_ptr = nullptr; // [nblocks * (npanels + 1)]
     int32_t *d_brow = nullptr;     // [nblocks + 1] first row of every block
     ValuesStamp stamp;             // which state of vals d_pvals is a copy of
+    // sorted blocks (mode 3, kernels_colsort.hip): blocks of <= 4096 rows streamed in column order, d_packed / d_pvals in
+    // units of 256 slots (four groups of 64 nonzeros with distinct rows)
+    bool sorted_mode = false;
+    int32_t *d_ubeg = nullptr;     // [nblocks + 1] first unit of every block
+    int32_t *d_usimple = nullptr;  // [nblocks] leading units of the block that hold groups (64 distinct rows per instruction)
+    int32_t *d_uend = nullptr;     // [nblocks] one past the last unit the block uses (groups, then its row-sorted tail)
+    int32_t *d_ubase = nullptr;    // [units] first column of every unit (packed holds offsets from it)
+    int32_t *d_tbeg = nullptr;     // [nblocks] first tail unit of the block in d_trow
+    uint16_t *d_trow = nullptr;    // [tail_units * 256] rows of the tail units (their packed words are whole columns)
+    int64_t tail_units = 0;
+    int sb_rows = 0, sb_waves = 0;   // rows per block (4096 | 8192), wavefronts per workgroup (8 | 4)
+    int64_t wide_blocks = 0;       // blocks whose short rows span more than 32768 lines of x (4 MiB)
+    int64_t units = 0;
+    int64_t lines = 0;             // occupied 128-byte lines of x, summed over the blocks (plan statistic)
+    int64_t tail = 0;              // nonzeros in the tails (long rows, what could not be grouped)
 };
 
 // SPMV_XSKIP (kernels_xskip.hip): the matrix in input-major segments per block of 1024 outputs
@@ -143,6 +158,8 @@ struct spmv_csr {
     spmv::ChunkPlan plan_adaptive; // SPMV_ADAPTIVE: 256-thread workgroups
     spmv::ChunkPlan plan_tiled;    // SPMV_TILED: workgroup size chosen from the column windows
     spmv::PanelPlan plan_panel;    // SPMV_PANEL
+    spmv::PanelPlan plan_auto_panel;   // SPMV_AUTO where it resolved to the panel family (its own: see refresh_panel)
+    bool auto_made_tiled = false;  // SPMV_AUTO made the TILED plan it looked at (and may release it)
     spmv::XskipPlan plan_xskip;    // SPMV_XSKIP
     int auto_variant = -1;         // SPMV_AUTO: the variant its plan chose (-1 = not planned)
     uint64_t values_gen = 0;       // bumped by spmv_csr_values_changed: plans that copied vals before that are stale
@@ -169,6 +186,19 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s);
 int plan_tiled_with(spmv_csr &h, int block, int maxpass, bool col16, hipStream_t s);
 int plan_adaptive_with(spmv_csr &h, int block, hipStream_t s);
 int plan_panel_with(spmv_csr &h, int pw_bits, int waves_per_launch, int mode, hipStream_t s);   // 0 = library default
+int build_panel(spmv_csr &h, PanelPlan &dst, int pw_bits, int waves_per_launch, int mode, hipStream_t s);
+int refresh_panel(spmv_csr &h, PanelPlan &dst, hipStream_t s);
+int launch_panel_plan(const spmv_csr &h, const PanelPlan &p, const float *x, float *y, hipStream_t s);
+// kernels_panel.hip helpers shared with kernels_colsort.hip
+int panel_row_blocks(const spmv_csr &h, int64_t nb0, int cap, hipStream_t s, DevPtr<int32_t> &brow, int32_t *nblocks);
+int panel_rowloc(const spmv_csr &h, const int32_t *d_brow, int nblocks, uint16_t *d_rowloc, hipStream_t s);
+// kernels_colsort.hip: SPMV_PANEL mode 3
+int plan_colsort(spmv_csr &h, PanelPlan &p, int want_rows, int want_waves, hipStream_t s);
+double colsort_model_cost(const PanelPlan &p, int64_t nnz);
+double colsort_cost(int rows_per_block, double lines_per_nnz, double tail_frac);
+int colsort_probe(const spmv_csr &h, hipStream_t s, double *long_frac, double *wide_frac, double *lines_per_nnz);
+int launch_colsort(const spmv_csr &h, const PanelPlan &p, const float *x, float *y, hipStream_t s);
+void destroy_colsort(PanelPlan &p);
 void destroy_plans(spmv_csr &h);
 void drop_tiled_plan(spmv_csr &h);   // SPMV_AUTO resolved to another variant: the TILED plan it looked at is released
 

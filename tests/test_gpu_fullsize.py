@@ -30,7 +30,10 @@ def test_config_2_and_3_full_size_every_row(pkg, oracle, gpu, name, band):
 # c5 = (128Mi)^2 with 2Gi nonzeros cut into 8 row blocks of 16Mi rows; ONE block is what one MI355X holds:
 # 16Mi rows x 128Mi columns, 2^28 nonzeros, the full 512 MiB x (2 818 572 292 bytes).  Blocks
 # k = 0 and k = 7 (first and last rows of the global matrix: band clipping at both ends, global row ids up to 2^27).
-BIG = [("c4", 0, 0), ("c4", 0, 1 << 16), ("c5", 0, 8192), ("c5", 7, 8192), ("c5", 0, 0), ("c5", 7, 0)]
+# ("c4", 0, 8192) is bench.py's headline workload itself (it was only covered by bench.py's parity_sample);
+# band 1 000 000 is where SPMV_AUTO takes the sorted blocks of the panel family (round 3).
+BIG = [("c4", 0, 8192), ("c4", 0, 0), ("c4", 0, 1 << 16), ("c4", 0, 1_000_000), ("c5", 0, 8192), ("c5", 7, 8192), ("c5", 0, 0),
+       ("c5", 7, 0)]
 
 
 @pytest.fixture(scope="module", params=BIG, ids=[f"{n}-block{k}-band{b}" for n, k, b in BIG])
@@ -96,7 +99,8 @@ def test_row_sample_matches_oracle(c4, pkg, oracle):
         assert np.array_equal(c4["d_ci"][k0:k1].cpu().numpy(), ci)                 # indices bit-exact
         assert np.array_equal(c4["d_va"][k0:k1].cpu().numpy().view(np.uint32), va.view(np.uint32))
         if w.band:                                                                  # the band follows the GLOBAL diagonal
-            assert ci.min() >= max(0, R0 + l0 - 4 * 3072 * 8) and ci.max() <= min(w.cols - 1, R0 + l1 + 4 * 3072 * 8)
+            half = max(4 * 3072 * 8, w.band)
+            assert ci.min() >= max(0, R0 + l0 - half) and ci.max() <= min(w.cols - 1, R0 + l1 + half)
         y_seq = oracle.spmv(rps, ci, va, x)
         y64, mag = oracle.spmv_f64(rps, ci, va, x)
         for name, y in ys.items():
@@ -120,9 +124,18 @@ def test_all_variants_agree_on_every_row(c4, pkg):
 
 
 def test_auto_choice_at_full_size(c4, pkg):
-    """SPMV_AUTO at the BASELINE sizes: the LDS-tiled kernel on banded columns, the panel sweep on uniform ones."""
+    """SPMV_AUTO at the BASELINE sizes: the LDS-tiled kernel on a band of 8192 columns, the panel sweep on uniform
+    columns, the sorted blocks of the panel family on a band of 1M columns (65 536: whichever the models price lower)."""
     d = c4["A"].plan_describe(pkg.capi.AUTO)
-    assert d.startswith("auto -> tiled" if c4["w"].band else "auto -> panel"), d
+    band = c4["w"].band
+    if band == 0:
+        assert d.startswith("auto -> panel: panel_columns="), d
+    elif band <= 8192:
+        assert d.startswith("auto -> tiled"), d
+    elif band >= 1_000_000:
+        assert d.startswith("auto -> panel: sorted_blocks="), d
+    else:
+        assert d.startswith("auto -> tiled") or d.startswith("auto -> panel: sorted_blocks="), d
 
 
 def test_linearity(c4, pkg):

@@ -47,11 +47,14 @@ def main():
         B = W.algorithmic_bytes(w.rows, w.cols, w.nnz)
         for vname in e["variants"]:
             v = capi.VARIANTS[vname]
+            import time as _t
+            torch.cuda.synchronize(); _t0 = _t.perf_counter()
             A.plan(v)
+            torch.cuda.synchronize(); plan_ms = (_t.perf_counter() - _t0) * 1e3
             A.time(v, d_x, d_y, 3)
             ms = min(A.time(v, d_x, d_y, e.get("iters", 30)) for _ in range(3))
             print(json.dumps(dict(dist=e["dist"], band=e["band"], rows=rows, variant=vname, env=e.get("env", {}), lib=e.get("lib", ""),
-                                  ms=round(ms, 4), GBs=round(B / ms / 1e6, 1), pct=round(B / ms / 1e6 / 80, 2),
+                                  ms=round(ms, 4), plan_ms=round(plan_ms, 2), GBs=round(B / ms / 1e6, 1), pct=round(B / ms / 1e6 / 80, 2),
                                   plan=A.plan_describe(v))), flush=True)
         A.close()
 

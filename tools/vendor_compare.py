@@ -60,6 +60,58 @@ class RocSparse:
         self.L.rocsparse_destroy_handle(self.h)
 
 
+def rocsparse_times(rs, rows, cols, nnz, d_rp, d_ci, d_va, d_x, d_y, iters=20, algs=None):
+    """{algorithm: (ms per SpMV, preprocess ms)} of rocsparse_spmv on device CSR arrays (torch tensors), every algorithm
+    preprocessed, HIP events on torch's current stream; an algorithm that reports an error is left out.  Used by main()
+    below and by bench.py (the vendor slot of the reference, src/kernels/cublas.cu:33, as a COMPARISON)."""
+    import torch
+    dev = d_x.device
+    one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
+    vx, vy = ctypes.c_void_p(), ctypes.c_void_p()
+    rs._ok(rs.L.rocsparse_create_dnvec_descr(ctypes.byref(vx), cols, d_x.data_ptr(), F32), "dnvec x")
+    rs._ok(rs.L.rocsparse_create_dnvec_descr(ctypes.byref(vy), rows, d_y.data_ptr(), F32), "dnvec y")
+    out = {}
+    for aname, alg in (algs or ALGS).items():
+        size = ctypes.c_size_t(0)
+        mat = ctypes.c_void_p()   # the analysis of an algorithm is cached INSIDE the matrix descriptor: a fresh one per algorithm
+        rs._ok(rs.L.rocsparse_create_csr_descr(ctypes.byref(mat), rows, cols, nnz, d_rp.data_ptr(), d_ci.data_ptr(),
+                                               d_va.data_ptr(), I32, I32, 0, F32), "create_csr")
+
+        def call(stage, buf, mat=mat, alg=alg, size=size):
+            return rs.L.rocsparse_spmv(rs.h, 111, ctypes.byref(one), mat, vx, ctypes.byref(zero), vy, F32, alg, stage,
+                                       ctypes.byref(size), buf)
+        ok = call(STAGE_SIZE, None) == 0
+        buf = None
+        if ok:
+            buf = torch.empty(max(int(size.value), 16), dtype=torch.uint8, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ok = call(STAGE_PREP, buf.data_ptr()) == 0
+            e1.record()
+            torch.cuda.synchronize()
+            prep_ms = e0.elapsed_time(e1)
+        if ok:
+            d_y.zero_()      # (NaN-prefilled y comes back NaN from some rocSPARSE algorithms even with beta = 0)
+            for _ in range(3):
+                ok = ok and call(STAGE_COMPUTE, buf.data_ptr()) == 0
+        if ok:
+            best = float("inf")
+            for _ in range(2):
+                e0.record()
+                for _ in range(iters):
+                    call(STAGE_COMPUTE, buf.data_ptr())
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / iters)
+            out[aname] = (best, prep_ms)
+        del buf
+        torch.cuda.synchronize()
+        rs.L.rocsparse_destroy_spmat_descr(mat)
+    rs.L.rocsparse_destroy_dnvec_descr(vx)
+    rs.L.rocsparse_destroy_dnvec_descr(vy)
+    return out
+
+
 def main():
     import torch
 
