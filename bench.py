@@ -102,7 +102,9 @@ def parse():
     ap.add_argument("--exchange", default=os.environ.get("SPMV_BENCH_EXCHANGE", "allgather"), choices=["allgather", "p2p"],
                     help="N>1: concatenate y with RCCL's all-gather (default) or with one direct send/recv pair per peer")
     ap.add_argument("--backend", default=os.environ.get("SPMV_BENCH_BACKEND", "nccl"),
-                    help="nccl (= RCCL, default) | gloo (rehearsal of the N>1 path with ranks sharing one GPU)")
+                    help="nccl (= RCCL through torch.distributed, default) | native (RCCL called from C++: libspmv_dist.so's "
+                         "pipelined step, include/spmv_dist.h; torch.distributed/gloo only carries the id, the barrier and the "
+                         "timing reduction) | gloo (rehearsal of the N>1 path with ranks sharing one GPU)")
     return ap.parse_args()
 
 
@@ -125,7 +127,8 @@ def main():
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: libspmv_hip has no CPU path")
     ndev = torch.cuda.device_count()
-    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    native = args.backend == "native"
+    dev_index = local_rank if args.backend in ("nccl", "native") else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -133,7 +136,7 @@ def main():
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group("gloo" if native else args.backend, rank=rank, world_size=world)
 
     variant = capi.VARIANTS[args.variant]
 
@@ -195,7 +198,7 @@ def main():
     rows_local = sub_rows * len(owned)
 
     exchange_only = None
-    if world == 1 and not strong:
+    if world == 1 and not strong and not native:
         A = handles[0]
         rp, d_rp, d_ci, d_va = keep[0]
         d_x = torch.empty(w.cols, dtype=torch.float32, device=dev)
@@ -213,7 +216,17 @@ def main():
     else:
         def bind(h):
             return lambda x, y: h.run(variant, x, y)
-        sh = pkg.dist.PipelinedSpmv(S, sub_rows, w.cols, [bind(h) for h in handles], dev, exchange=args.exchange)
+        if native:
+            # RCCL from C++ (include/spmv_dist.h): rank 0 makes the 128-byte id, gloo hands it round, every rank joins
+            idt = torch.zeros(pkg.dist_native.ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(pkg.dist_native.unique_id()), dtype=torch.uint8).clone()
+            if world > 1:
+                dist.broadcast(idt, src=0)
+            sh = pkg.dist_native.NativePipeline(world, rank, bytes(idt.numpy().tobytes()), S, sub_rows, w.cols, handles, variant, dev,
+                                                exchange=args.exchange)
+        else:
+            sh = pkg.dist.PipelinedSpmv(S, sub_rows, w.cols, [bind(h) for h in handles], dev, exchange=args.exchange)
         if rank == 0:
             capi.synth_x(w.seed, 0, w.cols, sh.x)
         if world > 1:
@@ -254,7 +267,7 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms_events = ev0.elapsed_time(ev1) / args.steps        # HIP events on the launch stream
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -267,7 +280,7 @@ def main():
     # ---- the kernel alone (no collective): mean launch time by HIP events on its stream -----------
     iters = max(10, args.steps)
     exchange_ms = None
-    if world == 1 and not strong:
+    if world == 1 and not strong and not native:
         kernel_ms = A.time(variant, d_x, d_y, iters)          # spmv_csr_time: events inside the library
     else:
         ev0.record()
@@ -310,7 +323,7 @@ def main():
         def _n(key):
             return int(plan_now.split(key + "=")[1].split()[0]) if key + "=" in plan_now else 0
         if resolved == "panel":
-            dom_kernel = "k_panel"
+            dom_kernel = "k_colsort" if "sorted_blocks=" in plan_now else "k_panel"
         elif resolved == "tiled" and (_n("col16_chunks") or _n("sorted_chunks")):
             # one launch: all chunks 16-bit -> k_tiled16, all sorted -> k_sorted, otherwise the three bodies in k_tiled_mixed
             dom_kernel = ("k_tiled16" if _n("col16_chunks") == _n("chunks") else
@@ -326,12 +339,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": w.describe(), "variant": args.variant,
                        "rows_per_gpu": rows_local, "nnz_per_gpu": nnz_local,
-                       "parallelism": "single GPU" if world == 1 and not strong else
+                       "parallelism": "single GPU" if world == 1 and not strong and not native else
                        f"{S} block-cyclic row blocks per rank x{world} ranks, all-gather(y) of group s "
                        f"({'RCCL all_gather' if args.exchange == 'allgather' else 'direct send/recv per peer'}) "
-                       f"overlapped with the multiply of block s+1, {args.backend}",
+                       f"overlapped with the multiply of block s+1, "
+                       f"{'RCCL called from C++ (libspmv_dist.so: spmv_dist_pipe_step)' if native else args.backend}",
                        "devices": (f"{world} ranks on {min(world, max(ndev, 1))} device(s)" +
-                                   ("" if ndev >= world and args.backend == "nccl" else
+                                   ("" if ndev >= world and args.backend in ("nccl", "native") else
                                     " -- RANKS SHARE DEVICES: a rehearsal of the plumbing, not a scaling measurement")),
                        "algorithmic_bytes_per_gpu": bytes_rank},
             "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBS, 2),
@@ -354,7 +368,7 @@ def main():
         }
 
     # ---- CPU baseline: rank 0, N = 1 only, bounded sample of the same matrix ------------------------
-    if rank == 0 and world == 1 and not strong and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not strong and not native and not args.no_cpu_baseline:
         orc = ge.load_oracle()
         n = min(args.cpu_sample_rows, rows_local)
         s0 = ((rows_local - n) // 2 // W.BLOCK_ROWS) * W.BLOCK_ROWS  # a window from the middle of the matrix
@@ -397,7 +411,7 @@ def main():
                                 "bit_identical_rows_vs_seq_oracle": int(np.sum(d_y[s0:s1].cpu().numpy() == y_cpu))}
 
     # ---- the other column laws and configs, kernel time only (N = 1) ------------------------------
-    if rank == 0 and world == 1 and not strong and not args.no_extras:
+    if rank == 0 and world == 1 and not strong and not native and not args.no_extras:
         del A, d_rp, d_ci, d_va, d_x, d_y, handles, keep
         torch.cuda.empty_cache()
         extras = []
@@ -480,11 +494,14 @@ def main():
                      "best_frac_of_peak": round(be / best[1] / 1e6 / HBM_PEAK_GBS, 4),
                      "algorithmic_bytes": be, **honest_fields(be, auto[1], nnz_e, n_loc, tx, auto_plan, tent),
                      **({"config_named_kernel": named_out} if named_out else {})}
-            if resolved in times:
+            if resolved == "tiled" and resolved in times:
                 entry["resolved_variant_kernel_ms"] = round(times[resolved], 5)   # the same plan timed under its own name
             if rocs is not None:
                 try:
-                    rt = vendor.rocsparse_times(rocs, n_loc, we.cols, nnz_e, e_rp, e_ci, e_va, e_x, e_y, iters=10)
+                    # (the two algorithms that were rocSPARSE's best on every workload of rounds 1 and 2; all four are in
+                    # tools/vendor_compare.py -> profiles/r02_vendor_compare.jsonl)
+                    rt = vendor.rocsparse_times(rocs, n_loc, we.cols, nnz_e, e_rp, e_ci, e_va, e_x, e_y, iters=10,
+                                                algs={k: vendor.ALGS[k] for k in ("csr_adaptive", "csr_nnzsplit")})
                     if rt:
                         ba = min(rt, key=lambda a: rt[a][0])
                         entry["rocsparse_best_ms"] = round(rt[ba][0], 5)
@@ -503,21 +520,35 @@ def main():
         t_y = torch.empty(N3, dtype=torch.float32, device=dev)
         A3 = capi.CsrMatrix.from_device(N3, N3, t_rp, t_ci, t_va)
         b3 = W.algorithmic_bytes(N3, N3, len(ci3))
-        best = None
-        for vn in ("auto", "adaptive"):
+        best, times3 = None, {}
+        for vn in ("adaptive", "tiled", "auto"):
             v = capi.VARIANTS[vn]
             A3.plan(v)
-            A3.time(v, t_x, t_y, 3)
-            ms = min(A3.time(v, t_x, t_y, 20) for _ in range(2))
+            A3.time(v, t_x, t_y, 10)
+            ms = min(A3.time(v, t_x, t_y, 20) for _ in range(3))
+            times3[vn] = ms
             if vn == "auto":
-                auto = (A3.plan_describe(v).split(":")[0], ms)
+                auto = (A3.plan_describe(v), ms)
             if best is None or ms < best[1]:
                 best = (vn, ms)
-        extras.append({"workload": f"stencil7: 7-point stencil on 200^3 = {N3} unknowns, nnz {len(ci3)} (host-built)",
-                       "auto": auto[0], "auto_kernel_ms": round(auto[1], 5),
-                       "auto_frac_of_peak": round(b3 / auto[1] / 1e6 / HBM_PEAK_GBS, 4),
-                       "best_variant": best[0], "best_kernel_ms": round(best[1], 5),
-                       "best_frac_of_peak": round(b3 / best[1] / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": b3})
+        e3 = {"workload": f"stencil7: 7-point stencil on 200^3 = {N3} unknowns, nnz {len(ci3)} (host-built)",
+              "auto": auto[0].split(":")[0], "auto_plan": auto[0], "auto_kernel_ms": round(auto[1], 5),
+              "auto_frac_of_peak": round(b3 / auto[1] / 1e6 / HBM_PEAK_GBS, 4),
+              "best_variant": best[0], "best_kernel_ms": round(best[1], 5),
+              "best_frac_of_peak": round(b3 / best[1] / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": b3,
+              **honest_fields(b3, auto[1], len(ci3), N3, touched_x_bytes(torch, t_ci, N3), auto[0], None)}
+        if rocs is not None:
+            try:
+                rt = vendor.rocsparse_times(rocs, N3, N3, len(ci3), t_rp, t_ci, t_va, t_x, t_y, iters=10,
+                                            algs={k: vendor.ALGS[k] for k in ("csr_adaptive", "csr_nnzsplit")})
+                if rt:
+                    ba = min(rt, key=lambda a: rt[a][0])
+                    e3["rocsparse_best_ms"] = round(rt[ba][0], 5)
+                    e3["rocsparse_best_algorithm"] = ba
+                    e3["speedup_vs_rocsparse_best"] = round(rt[ba][0] / auto[1], 2)
+            except Exception as ex:
+                e3["rocsparse_error"] = str(ex)[:120]
+        extras.append(e3)
         A3.close()
         out["other_workloads"] = extras
         # the headline's config under the other column laws, next to the headline (BASELINE fixes c4's sizes and

@@ -61,6 +61,44 @@ SPMV_API int spmv_dist_allgather_y(spmv_dist_t *d, float *d_y_full, void *stream
 
 SPMV_API int spmv_dist_destroy(spmv_dist_t *d);
 
+/* ---- the pipelined step (round 3): block-cyclic row blocks, the exchange of one block group under the multiply of the next
+ *
+ * The global row space is cut into S * world equal blocks of sub_rows rows; rank p owns blocks s*world + p, s = 0..S-1.
+ * Group s -- one block per rank -- is contiguous in the natural row order, so its concatenation lands in y_full in place:
+ * y_full[(s*world + p) * sub_rows ...] is rank p's slot of group s.  spmv_dist_pipe_step enqueues, for s = 0..S-1, the
+ * product of the rank's block s on `stream` and -- on a side stream of the pipe that waits for that product only -- the
+ * exchange of group s, which therefore runs while the CUs multiply block s+1.  Steps pipeline across calls: the product
+ * of block s waits only for the previous step's exchange of group s (it overwrites the slot that exchange read), so the
+ * exchange never drains inside a run of steps; spmv_dist_pipe_finish orders `stream` behind everything outstanding.
+ * (What bench.py --gpus N does with torch.distributed, spmv-test_amd/dist.py:PipelinedSpmv, for a C / C++ caller.)
+ *
+ * Exchange of a group:
+ *   SPMV_DIST_ALLGATHER   one in-place ncclAllGather (RCCL's collective: rings / trees over the xGMI mesh)
+ *   SPMV_DIST_P2P         one grouped ncclSend + ncclRecv pair per peer: every slice travels its owner's DIRECT xGMI link
+ *                         to each peer, all seven links of a GPU busy at once (the all-pairs schedule of SURVEY section 5)
+ *   SPMV_DIST_PEER_STORE  no RCCL: the owner copies its slice into every peer's y_full (hipMemcpyPeerAsync over xGMI; the
+ *                         "direct peer-store" of SURVEY section 8e "Overlap").  One-process model only: the ranks must
+ *                         be linked with spmv_dist_pipe_link, which hands every pipe its peers' buffers and events. */
+typedef struct spmv_dist_pipe spmv_dist_pipe_t;
+enum spmv_dist_exchange { SPMV_DIST_ALLGATHER = 0, SPMV_DIST_P2P = 1, SPMV_DIST_PEER_STORE = 2 };
+
+SPMV_API int spmv_dist_pipe_create(spmv_dist_t *d, int S, int64_t sub_rows, int64_t cols, int exchange, spmv_dist_pipe_t **out);
+/* PEER_STORE: all pipes of the job (index = rank), each with the y_full it will be stepped with.  Peer access is enabled
+ * between the devices that differ; ranks may share a device (rehearsal on one GPU: the copies are then device-local). */
+SPMV_API int spmv_dist_pipe_link(spmv_dist_pipe_t *const *pipes, float *const *d_y_full, int n);
+/* blocks[s] = the handle of this rank's s-th block (rows [(s*world + rank) * sub_rows, +sub_rows), all `cols` columns). */
+SPMV_API int spmv_dist_pipe_step(spmv_dist_pipe_t *p, spmv_csr_t *const *blocks, int variant, const float *d_x, float *d_y_full,
+                                 void *stream);
+/* The S exchanges of one step without the products (what the exchange alone costs). */
+SPMV_API int spmv_dist_pipe_exchange_only(spmv_dist_pipe_t *p, float *d_y_full, void *stream);
+SPMV_API int spmv_dist_pipe_finish(spmv_dist_pipe_t *p, void *stream);
+SPMV_API int spmv_dist_pipe_destroy(spmv_dist_pipe_t *p);
+
+/* Ranks WITHOUT an RCCL communicator, for SPMV_DIST_PEER_STORE only: one process drives them all; `devices` may name one
+ * device several times (the whole pipeline -- block-cyclic blocks, plan hand-over, peer stores, event ordering -- then
+ * runs on a single GPU, which is how the tests exercise world > 1 on a one-GPU box). */
+SPMV_API int spmv_dist_init_local(int nranks, const int *devices, spmv_dist_t **out /* nranks handles */);
+
 #ifdef __cplusplus
 }
 #endif

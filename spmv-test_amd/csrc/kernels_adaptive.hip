@@ -694,7 +694,11 @@ __device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh
     for (int j = 0; j < kVec; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) xv[j][q] = 0.0f;
+#ifdef SPMV_T_NOSTAGE   // (A/B builds only: the kernel without its x window -- results are wrong)
+    for (int off = 0; off < 0; off += kRegion) {
+#else
     for (int off = 0; off < wlen; off += kRegion) {
+#endif
         const int len = (wlen - off) < kRegion ? (wlen - off) : kRegion;
         const int64_t g0 = (int64_t)w0 + off;
         if (by_blocks) stage_blocks<BLOCK>(x, blk + (int64_t)c * kBlkMax + off / kBlkCols, len / kBlkCols, cols, smem, tid);
@@ -724,7 +728,11 @@ __device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh
         smem[p0 + 3] = vv[j][3] * xv[j][3];
     }
     __syncthreads();
+#ifdef SPMV_T_NOREDUCE  // (A/B builds only: the kernel without its row sums -- results are wrong)
+    if (tid <= m && rb0 == 0x7fffffff) y[lb0 + tid] = smem[tid] + (float)re0;
+#else
     reduce_chunk<BLOCK, true>(smem, sh, tid, c, lb0, m, base, lim, row_ptr, y, carry, rb0, re0);
+#endif
 }
 
 template <int BLOCK, bool BLOCKS>
@@ -1290,6 +1298,28 @@ static int build_col16(const spmv_csr &h, ChunkPlan &p, hipStream_t s)
     return SPMV_OK;
 }
 
+// how many chunks of the plan in `p` would stage a LIST of 256-column blocks in one pass (a counting run of k_plan_col16:
+// nothing is written)
+static int count_block_list_chunks(const spmv_csr &h, ChunkPlan &p, hipStream_t s, int *out)
+{
+    *out = 0;
+    if (p.nchunks == 0 || !p.d_win) return SPMV_OK;
+    DevPtr<int32_t> nblk, some;
+    SPMV_HIP_TRY(nblk.alloc(1));
+    SPMV_HIP_TRY(some.alloc(1));   // a non-null list pointer turns the block analysis on; a counting run never writes it
+    SPMV_HIP_TRY(hipMemsetAsync(nblk.p, 0, sizeof(int32_t), s));
+    int rc;
+    if (p.block == 256) rc = launch_plan_col16<256>(h, p, nullptr, nblk.p, some.p, 1, s);
+    else if (p.block == 512) rc = launch_plan_col16<512>(h, p, nullptr, nblk.p, some.p, 1, s);
+    else rc = launch_plan_col16<1024>(h, p, nullptr, nblk.p, some.p, 1, s);
+    if (rc) return rc;
+    int32_t cnt = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&cnt, nblk.p, sizeof cnt, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    *out = cnt;
+    return SPMV_OK;
+}
+
 template <int BLOCK>
 static int launch_plan_sorted(const spmv_csr &h, ChunkPlan &p, const int32_t *d_slot, hipStream_t s)
 {
@@ -1415,6 +1445,22 @@ int plan_adaptive(spmv_csr &h, bool tiled, hipStream_t s)
             int rc = build_plan(h, cands[k], default_passes(cands[k]), s, h.plan_tiled, &single, &full);
             if (rc) return rc;
             if (h.plan_tiled.nchunks == 0 || single >= 0.9 * h.plan_tiled.nchunks) return finish_tiled(h, true, s);
+        }
+        // Columns in a few clusters far apart (a 3-D stencil: r, r +- n, r +- n^2): no contiguous window holds a chunk's span,
+        // but a LIST of 256-column blocks does, in one pass -- then the smallest workgroup whose region holds the lists of
+        // >= 90 % of the chunks, like above (a 7-point stencil on 200^3 / 256^3 unknowns, forced sizes in one process: 256
+        // threads 72.0 / 77.8 % of peak, 512 71.5 / 76.1 %, 1024 64.6 / 69.3 %; round 1's timed trials picked 256 too.
+        // Round 2's prices know nothing of block lists and chose 1024: the regression of VERDICT round 2, item 1.)
+        {
+            bool want_blocks = true;
+            if (const char *e = getenv("SPMV_BLOCKS")) want_blocks = atoi(e) != 0;
+            for (int k = 0; k < 3 && want_blocks; ++k) {
+                int rc = build_plan(h, cands[k], default_passes(cands[k]), s, h.plan_tiled, nullptr, nullptr);
+                if (rc) return rc;
+                int lists = 0;
+                if ((rc = count_block_list_chunks(h, h.plan_tiled, s, &lists))) { free_plan(h.plan_tiled); return rc; }
+                if (lists >= 0.9 * h.plan_tiled.nchunks) return finish_tiled(h, true, s);
+            }
         }
         // no workgroup size stages (nearly) everything in one pass: compare the modelled cost of 512 threads / 8
         // passes and 1024 / 12 (a wide band gains from the larger chunk: more nonzeros per line of x; the inside of a

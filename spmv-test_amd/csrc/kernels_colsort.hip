@@ -565,7 +565,11 @@ __global__ __launch_bounds__(WAVES *kWave) void k_colsort(int nblocks, const int
                 const float *xb = x + r.base[j];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+#ifdef SPMV_CB_NOGATHER   // (A/B builds only: what the kernel costs without its gathers -- results are wrong)
+                    g.xv[j][q] = __int_as_float((int)(r.c[j][q] & 0xffu));
+#else
                     g.xv[j][q] = xb[r.c[j][q] & kCbColMask];
+#endif
                     g.row[j][q] = (int)(r.c[j][q] >> kCbColBits);
                     g.val[j][q] = r.v[j][q];
                 }
@@ -577,11 +581,18 @@ __global__ __launch_bounds__(WAVES *kWave) void k_colsort(int nblocks, const int
         for (int j = 0; j < kCbVec; ++j) {
             const int u = unit_of(st, j);
             if (u < us || u >= u1) {   // wave-uniform: a group -- every instruction holds 64 distinct rows (dummy rows included)
+#ifdef SPMV_CB_NOADD      // (A/B builds only: what the kernel costs without its LDS adds -- results are wrong)
+                float acc = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += g.val[j][q] * g.xv[j][q] + (float)g.row[j][q];
+                if (acc == 12345.678f) ys[lane] = acc;
+#else
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float t = ys[g.row[j][q]];
                     ys[g.row[j][q]] = t + g.val[j][q] * g.xv[j][q];
                 }
+#endif
             } else {
                 // the tail of the block: 64 CONSECUTIVE tail nonzeros per instruction, sorted by row -- runs of equal rows
                 // (the long rows) are folded by a segmented scan over the lanes, and the last lane of every run adds: those

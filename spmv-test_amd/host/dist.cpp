@@ -18,7 +18,22 @@ struct spmv_dist {
     std::vector<int64_t> bounds;   // world+1
     int64_t cols = 0;
     bool uniform = false;          // all blocks equal: one in-place ncclAllGather
-    int32_t *d_params = nullptr;   // 8 ints for spmv_dist_plan_like_root
+    int32_t *d_params = nullptr;   // status + 8 ints for spmv_dist_plan_like_root
+    bool local = false;            // spmv_dist_init_local: no communicator (SPMV_DIST_PEER_STORE only)
+};
+
+// One rank's side of the pipelined step (include/spmv_dist.h): the side stream the exchanges run on and, per block group,
+// the event behind its product (the exchange waits for it) and the event behind its exchange (the next step's product waits).
+struct spmv_dist_pipe {
+    spmv_dist *d = nullptr;
+    int S = 0, exchange = SPMV_DIST_ALLGATHER;
+    int64_t sub_rows = 0, cols = 0;
+    hipStream_t comm = nullptr;
+    std::vector<hipEvent_t> ev_mult, ev_done;
+    std::vector<char> pending;     // ev_done[s] has been recorded at least once
+    // PEER_STORE (spmv_dist_pipe_link): every rank's pipe and y_full, index = rank
+    std::vector<spmv_dist_pipe *> peers;
+    std::vector<float *> peer_y;
 };
 
 namespace {
@@ -81,7 +96,7 @@ int spmv_dist_init(int world, int rank, const void *id128, spmv_dist_t **out)
     std::memcpy(&id, id128, sizeof id);
     ncclResult_t r = ncclCommInitRank(&d->comm, world, id, rank);
     if (r != ncclSuccess) { delete d; return fail(SPMV_ERR_HIP, "ncclCommInitRank: %s", ncclGetErrorString(r)); }
-    if (hipMalloc((void **)&d->d_params, 8 * sizeof(int32_t)) != hipSuccess) { ncclCommDestroy(d->comm); delete d; return fail(SPMV_ERR_HIP, "hipMalloc"); }
+    if (hipMalloc((void **)&d->d_params, 9 * sizeof(int32_t)) != hipSuccess) { ncclCommDestroy(d->comm); delete d; return fail(SPMV_ERR_HIP, "hipMalloc"); }
     *out = d;
     return SPMV_OK;
 }
@@ -100,10 +115,25 @@ int spmv_dist_init_all(int ndev, const int *devices, spmv_dist_t **out)
         spmv_dist *d = new spmv_dist();
         d->comm = comms[i]; d->world = ndev; d->rank = i; d->device = devs[i];
         DIST_HIP(hipSetDevice(devs[i]));
-        DIST_HIP(hipMalloc((void **)&d->d_params, 8 * sizeof(int32_t)));
+        DIST_HIP(hipMalloc((void **)&d->d_params, 9 * sizeof(int32_t)));
         out[i] = d;
     }
     (void)hipSetDevice(prev);
+    return SPMV_OK;
+}
+
+int spmv_dist_init_local(int nranks, const int *devices, spmv_dist_t **out)
+{
+    if (!out || nranks < 1) return fail(SPMV_ERR_INVALID, "spmv_dist_init_local: bad argument");
+    const int ndev = spmv_device_count();
+    if (ndev < 1) return fail(SPMV_ERR_NO_DEVICE, "spmv_dist_init_local: no HIP device");
+    for (int i = 0; i < nranks; ++i) {
+        const int dev = devices ? devices[i] : i % ndev;
+        if (dev < 0 || dev >= ndev) return fail(SPMV_ERR_INVALID, "spmv_dist_init_local: device %d of rank %d is not visible", dev, i);
+        spmv_dist *d = new spmv_dist();
+        d->world = nranks; d->rank = i; d->device = dev; d->local = true;
+        out[i] = d;
+    }
     return SPMV_OK;
 }
 
@@ -136,6 +166,7 @@ int spmv_dist_set_partition(spmv_dist_t *d, const int64_t *row_bounds, int64_t c
 int spmv_dist_broadcast_x(spmv_dist_t *d, float *d_x, int root, void *stream)
 {
     if (!d || (!d_x && d->cols > 0) || root < 0 || root >= d->world) return fail(SPMV_ERR_INVALID, "spmv_dist_broadcast_x: bad argument");
+    if (d->local) return fail(SPMV_ERR_INVALID, "spmv_dist_broadcast_x: local ranks have no communicator (copy x with hipMemcpyPeerAsync)");
     if (int rc = require_device(d, "spmv_dist_broadcast_x")) return rc;
     if (d->cols == 0) return SPMV_OK;
     DIST_NCCL(ncclBroadcast(d_x, d_x, (size_t)d->cols, ncclFloat, root, d->comm, (hipStream_t)stream));
@@ -145,22 +176,28 @@ int spmv_dist_broadcast_x(spmv_dist_t *d, float *d_x, int root, void *stream)
 int spmv_dist_plan_like_root(spmv_dist_t *d, spmv_csr_t *shard, int variant, int root, void *stream)
 {
     if (!d || !shard || root < 0 || root >= d->world) return fail(SPMV_ERR_INVALID, "spmv_dist_plan_like_root: bad argument");
+    if (d->local) return fail(SPMV_ERR_INVALID, "spmv_dist_plan_like_root: local ranks carry plans with spmv_csr_plan_get / _set");
     if (int rc = require_device(d, "spmv_dist_plan_like_root")) return rc;
     hipStream_t s = (hipStream_t)stream;
-    int32_t params[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // nine numbers travel: the root's status first.  A root whose plan fails (XSKIP's table limit, PANEL's column limit on
+    // its shard only) still takes part in the broadcast -- the other ranks are already inside it and would wait for ever
+    //  -- and every rank returns the root's error.
+    int32_t msg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int root_rc = SPMV_OK;
     if (d->rank == root) {
-        int rc = spmv_csr_plan(shard, variant, stream);
-        if (rc == SPMV_OK) rc = spmv_csr_plan_get(shard, variant, params);
-        if (rc) return fail(rc, "spmv_dist_plan_like_root (root): %s", spmv_last_error());
-        DIST_HIP(hipMemcpyAsync(d->d_params, params, sizeof params, hipMemcpyHostToDevice, s));
+        root_rc = spmv_csr_plan(shard, variant, stream);
+        if (root_rc == SPMV_OK) root_rc = spmv_csr_plan_get(shard, variant, msg + 1);
+        if (root_rc) (void)fail(root_rc, "spmv_dist_plan_like_root (root): %s", spmv_last_error());
+        msg[0] = root_rc;
+        DIST_HIP(hipMemcpyAsync(d->d_params, msg, sizeof msg, hipMemcpyHostToDevice, s));
     }
-    DIST_NCCL(ncclBroadcast(d->d_params, d->d_params, 8, ncclInt32, root, d->comm, s));
-    if (d->rank != root) {
-        DIST_HIP(hipMemcpyAsync(params, d->d_params, sizeof params, hipMemcpyDeviceToHost, s));
-        DIST_HIP(hipStreamSynchronize(s));
-        const int rc = spmv_csr_plan_set(shard, variant, params, stream);
-        if (rc) return fail(rc, "spmv_dist_plan_like_root (rank %d): %s", d->rank, spmv_last_error());
-    }
+    DIST_NCCL(ncclBroadcast(d->d_params, d->d_params, 9, ncclInt32, root, d->comm, s));
+    if (d->rank == root) return root_rc;
+    DIST_HIP(hipMemcpyAsync(msg, d->d_params, sizeof msg, hipMemcpyDeviceToHost, s));
+    DIST_HIP(hipStreamSynchronize(s));
+    if (msg[0] != SPMV_OK) return fail(msg[0], "spmv_dist_plan_like_root (rank %d): the root's plan failed with status %d", d->rank, msg[0]);
+    const int rc = spmv_csr_plan_set(shard, variant, msg + 1, stream);
+    if (rc) return fail(rc, "spmv_dist_plan_like_root (rank %d): %s", d->rank, spmv_last_error());
     return SPMV_OK;
 }
 
@@ -169,6 +206,7 @@ int spmv_dist_allgather_y(spmv_dist_t *d, float *d_y_full, void *stream)
     if (!d || d->bounds.empty()) return fail(SPMV_ERR_INVALID, "spmv_dist_allgather_y: no partition set");
     if (int rc = require_device(d, "spmv_dist_allgather_y")) return rc;
     if (d->world == 1 || d->bounds.back() == 0) return SPMV_OK;
+    if (d->local) return fail(SPMV_ERR_INVALID, "spmv_dist_allgather_y: local ranks have no communicator (use a SPMV_DIST_PEER_STORE pipe)");
     if (!d_y_full) return fail(SPMV_ERR_INVALID, "spmv_dist_allgather_y: null y");
     hipStream_t s = (hipStream_t)stream;
     if (d->uniform) {
@@ -204,6 +242,187 @@ int spmv_dist_spmv(spmv_dist_t *d, spmv_csr_t *shard, int variant, const float *
         if (rc) return fail(rc, "spmv_dist_spmv: %s", spmv_last_error());
     }
     return spmv_dist_allgather_y(d, d_y_full, stream);
+}
+
+// ---- the pipelined step -------------------------------------------------------------------------------------------------
+int spmv_dist_pipe_create(spmv_dist_t *d, int S, int64_t sub_rows, int64_t cols, int exchange, spmv_dist_pipe_t **out)
+{
+    if (!d || !out || S < 1 || S > 4096 || sub_rows < 0 || cols < 0 || exchange < SPMV_DIST_ALLGATHER || exchange > SPMV_DIST_PEER_STORE)
+        return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_create: bad argument");
+    if (d->local && exchange != SPMV_DIST_PEER_STORE)
+        return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_create: local ranks (spmv_dist_init_local) exchange by peer stores only");
+    if ((int64_t)S * d->world * sub_rows >= (1ll << 40)) return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_create: too many rows");
+    if (int rc = require_device(d, "spmv_dist_pipe_create")) return rc;
+    spmv_dist_pipe *p = new spmv_dist_pipe();
+    p->d = d; p->S = S; p->sub_rows = sub_rows; p->cols = cols; p->exchange = exchange;
+    p->ev_mult.assign(S, nullptr);
+    p->ev_done.assign(S, nullptr);
+    p->pending.assign(S, 0);
+    hipError_t e = hipStreamCreateWithFlags(&p->comm, hipStreamNonBlocking);
+    for (int s = 0; s < S && e == hipSuccess; ++s) {
+        e = hipEventCreateWithFlags(&p->ev_mult[s], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_done[s], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        (void)spmv_dist_pipe_destroy(p);
+        return fail(SPMV_ERR_HIP, "spmv_dist_pipe_create: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return SPMV_OK;
+}
+
+int spmv_dist_pipe_link(spmv_dist_pipe_t *const *pipes, float *const *d_y_full, int n)
+{
+    if (!pipes || !d_y_full || n < 1) return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_link: bad argument");
+    for (int r = 0; r < n; ++r) {
+        const spmv_dist_pipe *p = pipes[r];
+        if (!p || !d_y_full[r] || p->d->world != n || p->d->rank != r || p->exchange != SPMV_DIST_PEER_STORE || p->S != pipes[0]->S ||
+            p->sub_rows != pipes[0]->sub_rows)
+            return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_link: entry %d is not rank %d's PEER_STORE pipe of this %d-rank job", r, r, n);
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int r = 0; r < n; ++r) {
+        spmv_dist_pipe *p = pipes[r];
+        p->peers.assign(pipes, pipes + n);
+        p->peer_y.assign(d_y_full, d_y_full + n);
+        for (int q = 0; q < n; ++q) {
+            const int a = p->d->device, b = pipes[q]->d->device;
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
+                (void)hipSetDevice(prev);
+                return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_link: device %d cannot access device %d", a, b);
+            }
+            (void)hipSetDevice(a);
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                (void)hipSetDevice(prev);
+                return fail(SPMV_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", a, b, hipGetErrorString(e));
+            }
+            (void)hipGetLastError();
+        }
+    }
+    (void)hipSetDevice(prev);
+    return SPMV_OK;
+}
+
+namespace {
+
+// the exchange of block group s on the pipe's side stream (which already waits for whatever must come first)
+int exchange_group(spmv_dist_pipe *p, int s, float *d_y_full)
+{
+    spmv_dist *d = p->d;
+    const int world = d->world;
+    if (world == 1 || p->sub_rows == 0) return SPMV_OK;
+    float *grp = d_y_full + (int64_t)s * world * p->sub_rows;
+    float *mine = grp + (int64_t)d->rank * p->sub_rows;
+    const size_t n = (size_t)p->sub_rows;
+    switch (p->exchange) {
+        case SPMV_DIST_ALLGATHER:      // in place: rank r's slot already holds its slice (sendbuff == recvbuff + rank * count)
+            DIST_NCCL(ncclAllGather(mine, grp, n, ncclFloat, d->comm, p->comm));
+            return SPMV_OK;
+        case SPMV_DIST_P2P: {
+            DIST_NCCL(ncclGroupStart());
+            for (int q = 0; q < world; ++q) {
+                if (q == d->rank) continue;
+                ncclResult_t e = ncclSend(mine, n, ncclFloat, q, d->comm, p->comm);
+                if (e == ncclSuccess) e = ncclRecv(grp + (int64_t)q * p->sub_rows, n, ncclFloat, q, d->comm, p->comm);
+                if (e != ncclSuccess) { (void)ncclGroupEnd(); return fail(SPMV_ERR_HIP, "ncclSend/ncclRecv(peer %d): %s", q, ncclGetErrorString(e)); }
+            }
+            DIST_NCCL(ncclGroupEnd());
+            return SPMV_OK;
+        }
+        default: {                     // PEER_STORE: my slice into the same place of every peer's y_full
+            if ((int)p->peers.size() != world) return fail(SPMV_ERR_INVALID, "SPMV_DIST_PEER_STORE: spmv_dist_pipe_link has not been called");
+            if (p->peer_y[d->rank] != d_y_full) return fail(SPMV_ERR_INVALID, "SPMV_DIST_PEER_STORE: y_full differs from the linked buffer");
+            const int64_t off = mine - d_y_full;
+            for (int k = 1; k < world; ++k) {   // start with the next rank: the owners do not all hit one peer at once
+                const int q = (d->rank + k) % world;
+                DIST_HIP(hipMemcpyPeerAsync(p->peer_y[q] + off, p->peers[q]->d->device, mine, d->device, n * sizeof(float), p->comm));
+            }
+            return SPMV_OK;
+        }
+    }
+}
+
+}  // namespace
+
+int spmv_dist_pipe_step(spmv_dist_pipe_t *p, spmv_csr_t *const *blocks, int variant, const float *d_x, float *d_y_full, void *stream)
+{
+    if (!p || !blocks || !d_y_full) return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_step: null argument");
+    spmv_dist *d = p->d;
+    if (int rc = require_device(d, "spmv_dist_pipe_step")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    for (int s = 0; s < p->S; ++s) {
+        int64_t rows = 0, cols = 0;
+        if (!blocks[s] || spmv_csr_dims(blocks[s], &rows, &cols, nullptr) != SPMV_OK || rows != p->sub_rows || cols != p->cols)
+            return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_step: block %d is not %lld x %lld", s, (long long)p->sub_rows, (long long)p->cols);
+        // the product overwrites the slot the previous step's exchange of this group read from
+        if (p->pending[s]) DIST_HIP(hipStreamWaitEvent(st, p->ev_done[s], 0));
+        float *slot = d_y_full + ((int64_t)s * d->world + d->rank) * p->sub_rows;
+        if (rows > 0) {
+            const int rc = spmv_csr_run(blocks[s], variant, d_x, slot, stream);
+            if (rc) return fail(rc, "spmv_dist_pipe_step (block %d): %s", s, spmv_last_error());
+        }
+        if (d->world > 1) {
+            DIST_HIP(hipEventRecord(p->ev_mult[s], st));
+            DIST_HIP(hipStreamWaitEvent(p->comm, p->ev_mult[s], 0));   // exchange s starts when product s is done
+            if (int rc = exchange_group(p, s, d_y_full)) return rc;
+            DIST_HIP(hipEventRecord(p->ev_done[s], p->comm));
+            p->pending[s] = 1;
+        }
+    }
+    return SPMV_OK;
+}
+
+int spmv_dist_pipe_exchange_only(spmv_dist_pipe_t *p, float *d_y_full, void *stream)
+{
+    if (!p || !d_y_full) return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_exchange_only: null argument");
+    spmv_dist *d = p->d;
+    if (int rc = require_device(d, "spmv_dist_pipe_exchange_only")) return rc;
+    if (d->world == 1) return SPMV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DIST_HIP(hipEventRecord(p->ev_mult[0], st));
+    DIST_HIP(hipStreamWaitEvent(p->comm, p->ev_mult[0], 0));
+    for (int s = 0; s < p->S; ++s) {
+        if (int rc = exchange_group(p, s, d_y_full)) return rc;
+        DIST_HIP(hipEventRecord(p->ev_done[s], p->comm));
+        p->pending[s] = 1;
+    }
+    return SPMV_OK;
+}
+
+int spmv_dist_pipe_finish(spmv_dist_pipe_t *p, void *stream)
+{
+    if (!p) return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_finish: null handle");
+    hipStream_t st = (hipStream_t)stream;
+    // RCCL: this rank's exchanges deliver everyone's slices.  Peer stores: a rank's y_full is filled by the OTHER ranks'
+    // side streams, so it waits for every rank's exchanges (events of one process order streams across devices).
+    if (p->exchange == SPMV_DIST_PEER_STORE && !p->peers.empty()) {
+        for (spmv_dist_pipe *q : p->peers)
+            for (int s = 0; s < q->S; ++s)
+                if (q->pending[s]) DIST_HIP(hipStreamWaitEvent(st, q->ev_done[s], 0));
+        return SPMV_OK;
+    }
+    for (int s = 0; s < p->S; ++s)
+        if (p->pending[s]) DIST_HIP(hipStreamWaitEvent(st, p->ev_done[s], 0));
+    return SPMV_OK;
+}
+
+int spmv_dist_pipe_destroy(spmv_dist_pipe_t *p)
+{
+    if (!p) return SPMV_OK;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(p->d->device);
+    if (p->comm) (void)hipStreamSynchronize(p->comm);
+    for (hipEvent_t e : p->ev_mult) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_done) if (e) (void)hipEventDestroy(e);
+    if (p->comm) (void)hipStreamDestroy(p->comm);
+    (void)hipSetDevice(prev);
+    delete p;
+    return SPMV_OK;
 }
 
 int spmv_dist_destroy(spmv_dist_t *d)

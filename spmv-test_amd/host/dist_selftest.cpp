@@ -2,9 +2,14 @@
 // (spmv_dist_init_all = ncclCommInitAll, the first process model of SURVEY.md section 8e), checked against the whole
 // matrix multiplied by a single handle.  Also the worked example of INTEGRATION.md for a C++ caller.
 //
-//   spmv_dist_selftest [--ranks N] [--rows-per-rank R] [--band B] [--unequal] [--variant tiled|adaptive|scalar] [--steps K]
+//   spmv_dist_selftest [--ranks N] [--rows-per-rank R] [--band B] [--unequal] [--variant tiled|adaptive|scalar|auto] [--steps K]
+//                      [--pipeline S] [--exchange allgather|p2p|peer] [--local]
 // N defaults to the number of visible GPUs.  Matrix: (N*R)^2, 16 nonzeros per row (config 2's law), generated on
 // the devices by spmv_synth_fill; with --unequal the blocks hold R-17, R+17, ... rows (the all-gather-v path).
+// --pipeline S (round 3): the pipelined step of spmv_dist.h -- every rank's R rows as S block-cyclic blocks, the exchange
+// of block group s on a side stream under the multiply of block s+1 -- with RCCL's all-gather, a grouped send/recv pair per
+// peer, or peer stores (hipMemcpyPeerAsync, no RCCL).  --local: ranks without a communicator (spmv_dist_init_local), as
+// many as asked on the visible devices round-robin -- the whole pipeline with world > 1 on a ONE-GPU box (peer stores only).
 // Prints one JSON line; exit code 0 iff every rank's y is bit-identical to the single-handle result.
 #include <hip/hip_runtime.h>
 
@@ -35,14 +40,21 @@ struct Rank {
     float *d_va = nullptr, *d_x = nullptr, *d_y = nullptr;
     spmv_csr_t *A = nullptr;
     hipStream_t stream = nullptr;
+    // --pipeline: S blocks of sub rows each (block-cyclic: block s of rank p = global block s*world + p)
+    std::vector<int32_t *> b_rp, b_ci;
+    std::vector<float *> b_va;
+    std::vector<spmv_csr_t *> blocks;
+    spmv_dist_pipe_t *pipe = nullptr;
 };
+
+static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local);
 
 int main(int argc, char **argv)
 {
     int ndev = spmv_device_count();
     int64_t per = 1 << 18, band = 4096;
-    bool unequal = false;
-    int variant = SPMV_TILED, steps = 20;
+    bool unequal = false, local = false;
+    int variant = SPMV_TILED, steps = 20, pipeline = 0, exchange = SPMV_DIST_ALLGATHER;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -51,12 +63,24 @@ int main(int argc, char **argv)
         else if (a == "--band") band = atoll(next());
         else if (a == "--steps") steps = atoi(next());
         else if (a == "--unequal") unequal = true;
+        else if (a == "--local") local = true;
+        else if (a == "--pipeline") pipeline = atoi(next());
+        else if (a == "--exchange") {
+            std::string v = next();
+            if (v == "allgather") exchange = SPMV_DIST_ALLGATHER;
+            else if (v == "p2p") exchange = SPMV_DIST_P2P;
+            else if (v == "peer") exchange = SPMV_DIST_PEER_STORE;
+            else { fprintf(stderr, "--exchange allgather|p2p|peer\n"); return 2; }
+        }
         else if (a == "--variant") {
             std::string v = next();
             variant = v == "adaptive" ? SPMV_ADAPTIVE : v == "scalar" ? SPMV_SCALAR : v == "auto" ? SPMV_AUTO : SPMV_TILED;
         } else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
-    if (ndev < 1 || ndev > spmv_device_count()) { fprintf(stderr, "HIP error: %d ranks asked, %d devices visible\n", ndev, spmv_device_count()); return EXIT_FAILURE; }
+    if (ndev < 1 || (!local && ndev > spmv_device_count())) { fprintf(stderr, "HIP error: %d ranks asked, %d devices visible\n", ndev, spmv_device_count()); return EXIT_FAILURE; }
+    if (local && spmv_device_count() < 1) { fprintf(stderr, "HIP error: no device visible\n"); return EXIT_FAILURE; }
+    if (pipeline > 0) return run_pipeline(ndev, per, band, variant, steps, pipeline, exchange, local);
+    if (local) { fprintf(stderr, "--local needs --pipeline S --exchange peer\n"); return 2; }
     const uint64_t seed = 20251031;
     const int64_t rows = per * ndev, cols = rows;
     const int nnz_row = 16;
@@ -185,6 +209,173 @@ int main(int argc, char **argv)
     for (int r = 0; r < ndev; ++r) {
         OK_HIP(hipSetDevice(rk[r].device));
         (void)spmv_csr_destroy(rk[r].A);
+        (void)spmv_dist_destroy(dist[r]);
+    }
+    (void)spmv_csr_destroy(whole);
+    return differing == 0 ? 0 : 1;
+}
+
+
+// ---- the pipelined step: S block-cyclic blocks per rank, exchange of group s under the multiply of block s+1 ------------
+static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local)
+{
+    if (S < 1 || per % S) { fprintf(stderr, "--rows-per-rank must be a multiple of --pipeline\n"); return 2; }
+    if (local && exchange != SPMV_DIST_PEER_STORE) { fprintf(stderr, "--local ranks exchange by peer stores only (--exchange peer)\n"); return 2; }
+    const uint64_t seed = 20251031;
+    const int64_t sub = per / S, rows = per * ndev, cols = rows;
+    const int nnz_row = 16;
+    std::vector<spmv_dist_t *> dist(ndev, nullptr);
+    if (local) OK_SPMV(spmv_dist_init_local(ndev, nullptr, dist.data()));
+    else OK_SPMV(spmv_dist_init_all(ndev, nullptr, dist.data()));
+    std::vector<Rank> rk(ndev);
+    std::vector<int32_t> rp(sub + 1);
+    for (int64_t i = 0; i <= sub; ++i) rp[i] = (int32_t)(i * nnz_row);
+    for (int r = 0; r < ndev; ++r) {
+        Rank &R = rk[r];
+        OK_SPMV(spmv_dist_rank(dist[r], nullptr, nullptr, &R.device));
+        OK_HIP(hipSetDevice(R.device));
+        OK_HIP(hipStreamCreate(&R.stream));
+        OK_HIP(hipMalloc((void **)&R.d_x, sizeof(float) * cols));
+        OK_HIP(hipMalloc((void **)&R.d_y, sizeof(float) * rows));
+        OK_HIP(hipMemset(R.d_y, 0xff, sizeof(float) * rows));                       // NaNs: every row must be overwritten
+        R.b_rp.assign(S, nullptr); R.b_ci.assign(S, nullptr); R.b_va.assign(S, nullptr); R.blocks.assign(S, nullptr);
+        for (int s = 0; s < S; ++s) {
+            const int64_t row0 = ((int64_t)s * ndev + r) * sub, nnz = sub * nnz_row;
+            OK_HIP(hipMalloc((void **)&R.b_rp[s], sizeof(int32_t) * (sub + 1)));
+            OK_HIP(hipMalloc((void **)&R.b_ci[s], sizeof(int32_t) * (nnz ? nnz : 1)));
+            OK_HIP(hipMalloc((void **)&R.b_va[s], sizeof(float) * (nnz ? nnz : 1)));
+            OK_HIP(hipMemcpy(R.b_rp[s], rp.data(), sizeof(int32_t) * (sub + 1), hipMemcpyHostToDevice));
+            OK_SPMV(spmv_synth_fill(seed, row0, sub, rows, cols, band, R.b_rp[s], R.b_ci[s], R.b_va[s], R.stream));
+            OK_SPMV(spmv_csr_create_device(sub, cols, nnz, R.b_rp[s], R.b_ci[s], R.b_va[s], &R.blocks[s]));
+        }
+        if (r == 0) OK_SPMV(spmv_synth_x(seed, 0, cols, R.d_x, R.stream));
+        OK_HIP(hipStreamSynchronize(R.stream));
+        OK_SPMV(spmv_dist_pipe_create(dist[r], S, sub, cols, exchange, &R.pipe));
+    }
+    // the dense vector, distributed once: RCCL broadcast, or (local ranks) a copy from rank 0
+    if (local) {
+        for (int r = 1; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            OK_HIP(hipMemcpyPeer(rk[r].d_x, rk[r].device, rk[0].d_x, rk[0].device, sizeof(float) * cols));
+        }
+    } else {
+        OK_SPMV(spmv_dist_group_start());
+        for (int r = 0; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            int64_t bounds_dummy[2] = {0, 0};
+            (void)bounds_dummy;
+            std::vector<int64_t> b(ndev + 1);
+            for (int q = 0; q <= ndev; ++q) b[q] = per * q;
+            OK_SPMV(spmv_dist_set_partition(dist[r], b.data(), cols));
+            OK_SPMV(spmv_dist_broadcast_x(dist[r], rk[r].d_x, 0, rk[r].stream));
+        }
+        OK_SPMV(spmv_dist_group_end());
+    }
+    if (exchange == SPMV_DIST_PEER_STORE) {
+        std::vector<spmv_dist_pipe_t *> pipes(ndev);
+        std::vector<float *> ys(ndev);
+        for (int r = 0; r < ndev; ++r) { pipes[r] = rk[r].pipe; ys[r] = rk[r].d_y; }
+        OK_SPMV(spmv_dist_pipe_link(pipes.data(), ys.data(), ndev));
+    }
+    // every block planned like rank 0's first
+    int32_t params[8];
+    OK_HIP(hipSetDevice(rk[0].device));
+    OK_SPMV(spmv_csr_plan(rk[0].blocks[0], variant, rk[0].stream));
+    OK_SPMV(spmv_csr_plan_get(rk[0].blocks[0], variant, params));
+    for (int r = 0; r < ndev; ++r)
+        for (int s = 0; s < S; ++s) {
+            if (r == 0 && s == 0) continue;
+            OK_HIP(hipSetDevice(rk[r].device));
+            OK_SPMV(spmv_csr_plan_set(rk[r].blocks[s], variant, params, rk[r].stream));
+        }
+    const bool rccl = exchange != SPMV_DIST_PEER_STORE;
+    auto step = [&]() {
+        if (rccl) OK_SPMV(spmv_dist_group_start());
+        for (int r = 0; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            OK_SPMV(spmv_dist_pipe_step(rk[r].pipe, rk[r].blocks.data(), variant, rk[r].d_x, rk[r].d_y, rk[r].stream));
+        }
+        if (rccl) OK_SPMV(spmv_dist_group_end());
+    };
+    auto finish_all = [&]() {
+        for (int r = 0; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_SPMV(spmv_dist_pipe_finish(rk[r].pipe, rk[r].stream)); }
+        for (int r = 0; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_HIP(hipStreamSynchronize(rk[r].stream)); }
+    };
+    step(); step(); step();      // three in a row: the cross-step ordering (product s waits for the last exchange of group s)
+    finish_all();
+
+    // the whole matrix through ONE handle on device 0, planned alike
+    OK_HIP(hipSetDevice(rk[0].device));
+    const int64_t nnz_all = rows * nnz_row;
+    std::vector<int32_t> rp_all(rows + 1);
+    for (int64_t i = 0; i <= rows; ++i) rp_all[i] = (int32_t)(i * nnz_row);
+    int32_t *d_rp, *d_ci;
+    float *d_va, *d_yref;
+    OK_HIP(hipMalloc((void **)&d_rp, sizeof(int32_t) * (rows + 1)));
+    OK_HIP(hipMalloc((void **)&d_ci, sizeof(int32_t) * nnz_all));
+    OK_HIP(hipMalloc((void **)&d_va, sizeof(float) * nnz_all));
+    OK_HIP(hipMalloc((void **)&d_yref, sizeof(float) * rows));
+    OK_HIP(hipMemcpy(d_rp, rp_all.data(), sizeof(int32_t) * (rows + 1), hipMemcpyHostToDevice));
+    OK_SPMV(spmv_synth_fill(seed, 0, rows, rows, cols, band, d_rp, d_ci, d_va, rk[0].stream));
+    spmv_csr_t *whole = nullptr;
+    OK_SPMV(spmv_csr_create_device(rows, cols, nnz_all, d_rp, d_ci, d_va, &whole));
+    OK_SPMV(spmv_csr_plan_set(whole, variant, params, rk[0].stream));
+    OK_SPMV(spmv_csr_run(whole, variant, rk[0].d_x, d_yref, rk[0].stream));
+    OK_HIP(hipStreamSynchronize(rk[0].stream));
+    std::vector<float> yref(rows), y(rows);
+    OK_HIP(hipMemcpy(yref.data(), d_yref, sizeof(float) * rows, hipMemcpyDeviceToHost));
+    int64_t differing = 0;
+    for (int r = 0; r < ndev; ++r) {
+        OK_HIP(hipSetDevice(rk[r].device));
+        OK_HIP(hipMemcpy(y.data(), rk[r].d_y, sizeof(float) * rows, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < rows; ++i) differing += std::memcmp(&y[i], &yref[i], sizeof(float)) != 0;
+    }
+
+    hipEvent_t e0, e1;
+    OK_HIP(hipSetDevice(rk[0].device));
+    OK_HIP(hipEventCreate(&e0));
+    OK_HIP(hipEventCreate(&e1));
+    auto timed = [&](auto &&body) {
+        finish_all();
+        OK_HIP(hipSetDevice(rk[0].device));
+        OK_HIP(hipEventRecord(e0, rk[0].stream));
+        for (int k = 0; k < steps; ++k) body();
+        for (int r = 0; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_SPMV(spmv_dist_pipe_finish(rk[r].pipe, rk[r].stream)); }
+        OK_HIP(hipSetDevice(rk[0].device));
+        OK_HIP(hipEventRecord(e1, rk[0].stream));
+        for (int r = 0; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_HIP(hipStreamSynchronize(rk[r].stream)); }
+        float ms = 0;
+        OK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return ms / steps;
+    };
+    const float step_ms = timed(step);
+    const float mult_ms = timed([&]() {
+        for (int r = 0; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            for (int s = 0; s < S; ++s)
+                OK_SPMV(spmv_csr_run(rk[r].blocks[s], variant, rk[r].d_x, rk[r].d_y + ((int64_t)s * ndev + r) * sub, rk[r].stream));
+        }
+    });
+    const float xchg_ms = timed([&]() {
+        if (rccl) OK_SPMV(spmv_dist_group_start());
+        for (int r = 0; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_SPMV(spmv_dist_pipe_exchange_only(rk[r].pipe, rk[r].d_y, rk[r].stream)); }
+        if (rccl) OK_SPMV(spmv_dist_group_end());
+    });
+    char plan[256];
+    OK_HIP(hipSetDevice(rk[0].device));
+    OK_SPMV(spmv_csr_plan_describe(rk[0].blocks[0], variant, plan, sizeof plan));
+    const double bytes = 8.0 * nnz_all + 4.0 * (rows + (double)ndev * S) + 4.0 * rows + 4.0 * cols * ndev;
+    const char *xname = exchange == SPMV_DIST_ALLGATHER ? "allgather" : exchange == SPMV_DIST_P2P ? "p2p" : "peer";
+    printf("{\"world\": %d, \"process_model\": \"%s\", \"pipeline_blocks_per_rank\": %d, \"exchange\": \"%s\", \"rows\": %lld, "
+           "\"nnz\": %lld, \"band\": %lld, \"variant\": \"%s\", \"rows_differing_from_single_handle\": %lld, \"step_ms\": %.5f, "
+           "\"multiply_only_ms\": %.5f, \"exchange_only_ms\": %.5f, \"aggregate_GBs\": %.1f, \"plan\": \"%s\"}\n",
+           ndev, local ? "one process, local ranks (no communicator), devices round-robin" : "one process, ncclCommInitAll", S, xname,
+           (long long)rows, (long long)nnz_all, (long long)band, spmv_variant_name(variant), (long long)differing, step_ms, mult_ms,
+           xchg_ms, bytes / (step_ms * 1e-3) / 1e9, plan);
+    for (int r = 0; r < ndev; ++r) {
+        OK_HIP(hipSetDevice(rk[r].device));
+        (void)spmv_dist_pipe_destroy(rk[r].pipe);
+        for (int s = 0; s < S; ++s) (void)spmv_csr_destroy(rk[r].blocks[s]);
         (void)spmv_dist_destroy(dist[r]);
     }
     (void)spmv_csr_destroy(whole);

@@ -264,3 +264,33 @@ def test_dist_selftest_world_of_one_gpu(pkg, gpu):
         assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
         out = json.loads(p.stdout.strip().splitlines()[-1])
         assert out["world"] == n and out["rows_differing_from_single_handle"] == 0 and out["step_ms"] > 0
+
+
+@pytest.mark.parametrize("args", [
+    ["--pipeline", "4", "--exchange", "allgather"],                                  # RCCL communicator over the visible GPUs
+    ["--pipeline", "4", "--exchange", "p2p", "--variant", "auto", "--band", "0"],
+    ["--local", "--ranks", "4", "--pipeline", "4", "--exchange", "peer"],           # world 4 on ONE GPU: peer stores, no RCCL
+    ["--local", "--ranks", "3", "--pipeline", "2", "--exchange", "peer", "--variant", "adaptive", "--band", "200000"],
+    ["--local", "--ranks", "2", "--pipeline", "1", "--exchange", "peer", "--variant", "auto", "--band", "200000",
+     "--rows-per-rank", str(1 << 20)],
+], ids=["allgather", "p2p-auto", "peer-4ranks", "peer-3ranks", "peer-sorted-blocks"])
+def test_dist_pipeline_selftest(pkg, gpu, args):
+    """The pipelined step of include/spmv_dist.h from C++: S block-cyclic row blocks per rank, the
+    exchange of block group s on a side stream under the multiply of block s+1, three steps back to back, every rank's y
+    bit-identical to the whole matrix through a single handle planned alike.  With RCCL the world is the visible GPUs (one
+    here); with --local the ranks have no communicator and exchange by peer stores, so world > 1 -- block-cyclic offsets,
+    plan hand-over, cross-rank event ordering -- runs on this one GPU."""
+    import json
+    import subprocess
+    import torch
+    cmd = [str(pkg.capi.DIST_SELFTEST_PATH)] + args
+    if "--local" not in args:
+        cmd += ["--ranks", str(torch.cuda.device_count())]
+    if "--rows-per-rank" not in args:
+        cmd += ["--rows-per-rank", str(1 << 18)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["rows_differing_from_single_handle"] == 0 and out["step_ms"] > 0
+    if "--local" in args:
+        assert out["world"] == int(args[args.index("--ranks") + 1]) and out["exchange"] == "peer"

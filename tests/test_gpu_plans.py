@@ -251,3 +251,26 @@ def test_panel_lds_mode_edge_shapes(pkg, oracle, gpu):
         y64, mag = oracle.spmv_f64(rp, ci, va, x)
         assert_close_to_oracle(y, y64, mag, f"panel LDS {rows}x{cols}")
         prob.A.close()
+
+
+def test_clustered_columns_take_the_block_list_plan(pkg, oracle, gpu):
+    """a 7-point 3-D stencil (columns r, r+-1, r+-n, r+-n^2: three clusters 2 n^2 apart, no
+    contiguous window holds a chunk's span) must get the plan round 1's timed trials picked -- lists of 256-column
+    blocks staged in one pass, by the smallest workgroup that holds them -- not the 1024-thread plan the prices of round 2
+    chose (0.714 -> 0.638 of peak on 200^3).  Pins the choice; the numbers are in profiles/r03_stencil_plans.jsonl."""
+    capi, W = pkg.capi, pkg.workloads
+    N, rp, ci, va = W.stencil7(128)
+    x = np.random.Generator(np.random.PCG64(128)).uniform(-1, 1, size=N).astype(np.float32)
+    prob = DeviceProblem(pkg, gpu, N, N, rp, ci, va, x)
+    for v in (capi.TILED, capi.AUTO):
+        y = prob.run(v)
+        d = prob.A.plan_describe(v)
+        fields = dict(f.split("=") for f in d.split(": ")[-1].split() if "=" in f)
+        assert fields["block"] == "256", d
+        assert int(fields["block_list_chunks"]) >= 0.9 * int(fields["chunks"]), d
+        assert int(fields["sorted_chunks"]) == 0, d
+        if v == capi.AUTO:
+            assert d.startswith("auto -> tiled"), d
+        y64, mag = oracle.spmv_f64(rp, ci, va, x)
+        assert_close_to_oracle(y, y64, mag, d)
+    prob.A.close()

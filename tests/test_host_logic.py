@@ -47,6 +47,8 @@ def test_dist_library_exports_every_declared_symbol(pkg):
                          check=True).stdout
     syms = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
     assert syms == declared
+    # and the Python binding bench.py --backend native drives it with covers exactly the header
+    assert sorted(pkg.dist_native.SIGNATURES) == declared
 
 
 @pytest.mark.skipif(not _no_gpu_early(), reason="only meaningful on a box without a GPU")

@@ -66,7 +66,7 @@ def main():
         kernels[k] = {"launches": n, "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
                       "hbm_bytes_per_launch": int(round((2 * f_kib + w_kib) * 1024))}
     # the plan autotunes over several instantiations of k_adaptive: the timed one has the most launches
-    hot = ("k_panel(",) if variant == "panel" else ("k_adaptive", "k_tiled16", "k_tiled_mixed", "k_sorted")
+    hot = ("k_panel(", "k_colsort") if variant == "panel" else ("k_adaptive", "k_tiled16", "k_tiled_mixed", "k_sorted")
     dom = max((k for k in kernels if any(h in k for h in hot)), key=lambda k: kernels[k]["launches"])
     # the panel sweep covers the matrix in several launches of the same kernel ("launches=N" in the plan string):
     # scale the per-launch counters to one SpMV so they compare with the algorithmic bytes of one SpMV
