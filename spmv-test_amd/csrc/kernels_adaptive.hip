@@ -300,6 +300,11 @@ struct ChunkShared {
 //   17..kHugeSeg: queued in LDS with their bounds, summed by kGroup-lane groups (__shfl_down tree);
 //   longer (a power-law row can fill the chunk): one wavefront each.
 // PREF: this lane's first row bounds were prefetched into rb0/re0.
+// (Round 3, tried and dropped: summing the segments longer than kHugeSeg from the products every lane still holds in
+// registers, by all wavefronts at once instead of one wavefront per segment reading LDS.  Slower on power-law rows -- c3 band
+// 8192 0.2409 ms against 0.2309, a chunk holds up to 16 such segments and every lane then runs 16 compare-and-adds per
+// segment -- and its 2 KiB of partials pushed the 1024-thread workgroup from two per CU to one (band 65 536: 0.49 -> 0.67 ms):
+// the static LDS beside the region is budgeted to the last half KiB.  profiles/r03_huge_segments_from_registers_ab.jsonl)
 template <int BLOCK, bool PREF>
 __device__ __forceinline__ void reduce_chunk(const float *smem, ChunkShared<BLOCK> &sh, int tid, int c, int lb0, int m,
                                              int64_t base, int64_t lim, const int32_t *__restrict__ row_ptr,

@@ -54,15 +54,15 @@ __device__ __forceinline__ float scalar_row_by_wave(int lane, int32_t b, int32_t
 // products in LDS, and every thread then adds ITS row's products in order.  A naive thread-per-row
 // loop reads col_idx/vals at a stride of one row per lane (4-byte loads, 64 cache lines per wave
 // instruction); a workgroup whose rows hold more than kScalarCap nonzeros falls back to that loop.
-constexpr int kScalarCap = 8192;  // products staged per workgroup
-constexpr int kScalarWin = 9216;  // floats of LDS per workgroup (36 KiB -> 4 workgroups per CU): the products, or first the x window
-constexpr int kScalarFast = 4096; // nonzeros per workgroup up to which the fast path below keeps everything in registers
-constexpr int kScalarVec = kScalarFast / 4 / kBlock + 1;   // 16-byte vectors per thread (+1: a range that starts unaligned)
+// (Round 3, tried and dropped, A/B in one process -- profiles/r03_scalar_ab.jsonl: (1) a fast path for workgroups of <= 4096
+// nonzeros with 16-byte streams kept in registers and a plan-free LDS window of x between the range's min and max column:
+// config 2 band 8192 0.0525 ms against 0.0457, uniform 0.0994 against 0.0919 -- the window adds two barriers and a round trip
+// to a kernel that is a chain of dependent round trips per workgroup; (2) the same without the window: 0.0483; (3) four
+// loads in flight per trip: 0.0546; (4) 16 KiB of LDS for 8 workgroups per CU: 0.0460; (5) a pad word per 32 products
+// against the stride-16 bank pattern of config 2's rows: 0.0449.  None moves it: 40 % of peak at config 2 band 8192.)
+constexpr int kScalarCap = 8192;  // products staged per workgroup (32 KiB of LDS -> 5 workgroups per CU)
 
-using i4 = int __attribute__((ext_vector_type(4)));
-using f4 = float __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(kBlock) void k_scalar(int64_t rows, int64_t cols, const int32_t *__restrict__ row_ptr,
+__global__ __launch_bounds__(kBlock) void k_scalar(int64_t rows, const int32_t *__restrict__ row_ptr,
                                                    const int32_t *__restrict__ col_idx,
                                                    const float *__restrict__ vals,
                                                    const float *__restrict__ x, float *__restrict__ y)
@@ -70,112 +70,13 @@ __global__ __launch_bounds__(kBlock) void k_scalar(int64_t rows, int64_t cols, c
     // two roundings per term, like the host loop: HIP's __fmul_rn/__fadd_rn are plain operators
     // that hipcc would contract into v_fma_f32 under its default -ffp-contract=fast
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float prod[kScalarWin];
-    __shared__ int s_mn[kBlock / kWave], s_mx[kBlock / kWave];
+    __shared__ float prod[kScalarCap];
     const int64_t r0 = (int64_t)blockIdx.x * kBlock;
     const int64_t r = r0 + threadIdx.x;
     const int64_t rend = (r0 + kBlock < rows) ? r0 + kBlock : rows;
     const int32_t wb = row_ptr[r0], we = row_ptr[rend];  // the workgroup's nonzero range
     const int32_t b = r < rows ? row_ptr[r] : 0, e = r < rows ? row_ptr[r + 1] : 0;
-    if (we - wb <= kScalarFast) {
-        // Fast path (round 3; config 2 itself: 256 rows x 16): the range is streamed with 16-byte loads (a wave
-        // instruction covers 1 KiB instead of 256 B: the 4-byte form spent most of its time in the address unit), kept in
-        // registers, and when its columns span no more than the LDS buffer the window of x is staged there first (LDS-DMA)
-        // and the gathers become LDS reads -- the north-star's "LDS-staged tiles of the dense input vector", plan-free: the
-        // window is the range's own min / max column.  The products then take the window's place.  Same products, same
-        // order of every sum as the loop below: y stays bit-identical to the oracle.
-        const int32_t a0 = wb & ~3;
-        const int nvec = (we - a0 + 3) >> 2;                       // <= 1025
-        const i4 *c4 = reinterpret_cast<const i4 *>(col_idx + a0);
-        const f4 *v4 = reinterpret_cast<const f4 *>(vals + a0);
-        i4 cc[kScalarVec];
-        f4 vv[kScalarVec];
-        int mn = 0x7fffffff, mx = -1;
-#pragma unroll
-        for (int j = 0; j < kScalarVec; ++j) {
-            const int v = j * kBlock + (int)threadIdx.x;
-            cc[j] = i4{0, 0, 0, 0};
-            vv[j] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (v < nvec) {
-                // (the last vector may reach past nnz by up to 3 elements: inside the arrays' 16-byte granule? not
-                // guaranteed -- the tail vector is read element by element)
-                if (a0 + 4 * v + 3 < we) {
-                    cc[j] = __builtin_nontemporal_load(&c4[v]);
-                    vv[j] = __builtin_nontemporal_load(&v4[v]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (a0 + 4 * v + q < we) { cc[j][q] = col_idx[a0 + 4 * v + q]; vv[j][q] = vals[a0 + 4 * v + q]; }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = a0 + 4 * v + q;
-                    if (k >= wb && k < we) {
-                        mn = cc[j][q] < mn ? cc[j][q] : mn;
-                        mx = cc[j][q] > mx ? cc[j][q] : mx;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) {
-            const int a = __shfl_down(mn, o, kWave), c = __shfl_down(mx, o, kWave);
-            mn = a < mn ? a : mn;
-            mx = c > mx ? c : mx;
-        }
-        if ((threadIdx.x & (kWave - 1)) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
-        __syncthreads();
-        mn = s_mn[0]; mx = s_mx[0];
-#pragma unroll
-        for (int w = 1; w < kBlock / kWave; ++w) {
-            mn = s_mn[w] < mn ? s_mn[w] : mn;
-            mx = s_mx[w] > mx ? s_mx[w] : mx;
-        }
-        const int w0 = mn & ~3;
-        const bool staged = mx >= 0 && (int64_t)mx + 1 - w0 <= kScalarWin;   // workgroup-uniform
-        f4 xv[kScalarVec];
-        if (staged) {
-            const int len = mx + 1 - w0;
-            if ((int64_t)w0 + len + 3 < cols) {
-                for (int i = (int)threadIdx.x * 4; i < len; i += kBlock * 4) __builtin_amdgcn_global_load_lds(x + w0 + i, prod + i, 16, 0, 0);
-            } else {
-                for (int i = (int)threadIdx.x; i < len; i += kBlock) prod[i] = x[w0 + i];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kScalarVec; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = a0 + 4 * (j * kBlock + (int)threadIdx.x) + q;
-                    xv[j][q] = (k >= wb && k < we) ? prod[cc[j][q] - w0] : 0.0f;
-                }
-            __syncthreads();   // every gather has its value before the products overwrite the window
-        } else {
-#pragma unroll
-            for (int j = 0; j < kScalarVec; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = a0 + 4 * (j * kBlock + (int)threadIdx.x) + q;
-                    xv[j][q] = (k >= wb && k < we) ? x[cc[j][q]] : 0.0f;
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < kScalarVec; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = a0 + 4 * (j * kBlock + (int)threadIdx.x) + q;
-                if (k >= wb && k < we) {
-                    const float p = xv[j][q] * vv[j][q];
-                    prod[k - wb] = p;
-                }
-            }
-        __syncthreads();
-        if (r < rows) {
-            float acc = 0.0f;
-            for (int32_t k = b; k < e; ++k) acc = acc + prod[k - wb];
-            y[r] = acc;
-        }
-    } else if (we - wb <= kScalarCap) {
+    if (we - wb <= kScalarCap) {
         for (int32_t k = wb + (int32_t)threadIdx.x; k < we; k += kBlock) {
             const float p = x[col_idx[k]] * vals[k];
             prod[k - wb] = p;
@@ -400,7 +301,7 @@ int launch_scalar(const spmv_csr &h, const float *x, float *y, hipStream_t s)
                            h.d_col_idx, h.d_vals, x, y);
         return check_launch("k_scalar_long");
     }
-    hipLaunchKernelGGL(k_scalar, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.cols, h.d_row_ptr,
+    hipLaunchKernelGGL(k_scalar, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
                        h.d_col_idx, h.d_vals, x, y);
     return check_launch("k_scalar");
 }
