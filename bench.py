@@ -86,7 +86,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--variant", default=os.environ.get("SPMV_BENCH_VARIANT", "auto"),
                     help="auto (default: the library picks tiled or panel from the matrix) | tiled | panel | adaptive | ...")
-    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"], help="N=1 workload (default: c4)")
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5shard"],
+                    help="N=1 workload (default: c4); c5shard = rows [0,16Mi) of config 5's (128Mi)^2 matrix with all 128Mi columns "
+                         "and the full 512 MiB x: what ONE MI355X of the 8 multiplies")
     ap.add_argument("--band", type=int, default=int(os.environ.get("SPMV_BENCH_BAND", "8192")),
                     help="column law: >0 = diagonal band of that many columns (default 8192), 0 = uniform random")
     ap.add_argument("--no-extras", action="store_true", help="skip the other column laws / configs (N=1 only)")
@@ -109,6 +111,7 @@ def parse():
 
 
 def main():
+    t_main = time.perf_counter()
     args = parse()
     import torch
     import torch.distributed as dist
@@ -152,6 +155,10 @@ def main():
         S = args.total_blocks // world
         sub_rows = w.rows // args.total_blocks
         owned = [s * world + rank for s in range(S)]
+    elif world == 1 and args.config == "c5shard":
+        w = W.c5(8, band=args.band)
+        sub_rows = 16 << 20
+        owned = [0]
     elif world == 1:
         w = W.config(args.config, band=args.band)
         sub_rows = w.rows
@@ -337,7 +344,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": w.describe(), "variant": args.variant,
+            "config": {"workload": w.describe() + (" -- the per-GPU shard: rows [0,16Mi), all columns, the full x"
+                                                    if world == 1 and args.config == "c5shard" else ""),
+                       "variant": args.variant,
                        "rows_per_gpu": rows_local, "nnz_per_gpu": nnz_local,
                        "parallelism": "single GPU" if world == 1 and not strong and not native else
                        f"{S} block-cyclic row blocks per rank x{world} ranks, all-gather(y) of group s "
@@ -367,6 +376,8 @@ def main():
             "setup_s": round(setup_s, 2),
         }
 
+    if rank == 0:
+        print(f"[bench] headline measured at {time.perf_counter() - t_main:.1f} s", file=sys.stderr, flush=True)
     # ---- CPU baseline: rank 0, N = 1 only, bounded sample of the same matrix ------------------------
     if rank == 0 and world == 1 and not strong and not native and not args.no_cpu_baseline:
         orc = ge.load_oracle()
@@ -434,9 +445,11 @@ def main():
             rocs = None
         todo = [("c4", 0), ("c4", 2048), ("c4", 65536), ("c4", 200000), ("c4", 1000000), ("c2", 0), ("c2", 8192), ("c3", 0),
                 ("c3", 8192), ("c5", 8192), ("c5", 0)]
+        print(f"[bench] cpu baseline done at {time.perf_counter() - t_main:.1f} s", file=sys.stderr, flush=True)
         for cname, band in todo:
             if cname == args.config and band == args.band:
                 continue
+            t_w = time.perf_counter()
             if cname == "c5":
                 # config 5's per-GPU shard: rows [0, 16Mi) of the (128Mi)^2 matrix, all 128Mi columns, the full
                 # 512 MiB x (2 818 572 292 algorithmic bytes) -- what ONE MI355X of the 8 multiplies
@@ -467,7 +480,7 @@ def main():
                 return min(Ae.time(v, e_x, e_y, iters) for _ in range(groups))
             best, auto = None, None
             times = {}
-            for vn in ("adaptive", "tiled", "vector") + (("panel",) if band == 0 else ()) + ("auto",):
+            for vn in ("adaptive", "tiled") + (("panel",) if band == 0 else ()) + ("auto",):
                 ms = timed(capi.VARIANTS[vn])
                 times[vn] = ms
                 if vn == "auto":
@@ -483,7 +496,7 @@ def main():
                 ms = timed(capi.VARIANTS[vn], iters=10, groups=2)
                 named_out[vn] = {"kernel_ms": round(ms, 5), "frac_of_peak": round(be / ms / 1e6 / HBM_PEAK_GBS, 4)}
             tx = touched_x_bytes(torch, e_ci, we.cols)
-            tkey = f"{resolved}:{cname}:band{band}"
+            tkey = f"{resolved}:{'c5x8' if cname == 'c5' else cname}:band{band}"
             tent = traffic_all.get(tkey)
             if tent is not None and tent.get("plan", "").split(": ", 1)[-1] != auto_plan.split(": ", 1)[-1]:
                 tent = None                                      # taken with another plan: not replayed
@@ -510,10 +523,12 @@ def main():
                 except Exception as ex:                      # a comparison, never a reason to lose the line
                     entry["rocsparse_error"] = str(ex)[:120]
             extras.append(entry)
+            print(f"[bench] {cname} band {band}: {time.perf_counter() - t_w:.1f} s", file=sys.stderr, flush=True)
             Ae.close()
             del e_rp, e_ci, e_va, e_x, e_y
             torch.cuda.empty_cache()
         # a structure the synthetic laws do not cover: a 7-point 3-D stencil (three column clusters 2*200^2 apart)
+        print(f"[bench] synthetic extras done at {time.perf_counter() - t_main:.1f} s", file=sys.stderr, flush=True)
         N3, rp3, ci3, va3 = W.stencil7(200)
         t_rp, t_ci, t_va = (torch.from_numpy(a).to(dev) for a in (rp3, ci3, va3))
         t_x = torch.rand(N3, device=dev) * 2 - 1
@@ -562,6 +577,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
+        print(f"[bench] total {time.perf_counter() - t_main:.1f} s in the process", file=sys.stderr, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

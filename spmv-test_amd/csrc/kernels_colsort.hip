@@ -667,19 +667,33 @@ __global__ __launch_bounds__(kBlock) void k_cb_probe(int64_t rows, const int32_t
 {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     unsigned long long mine = 0ull;
+    int lo = INT_MAX, hi = -1;
     if (r < rows) {
         const int32_t a = row_ptr[r], b = row_ptr[r + 1];
         if (b - a > 256) {
             mine = (unsigned long long)(b - a);
         } else if (b > a) {
             const int32_t c0 = col_idx[a], c1 = col_idx[b - 1];
-            atomicMin(&bmin[r >> 12], c0 < c1 ? c0 : c1);
-            atomicMax(&bmax[r >> 12], c0 > c1 ? c0 : c1);
+            lo = c0 < c1 ? c0 : c1;
+            hi = c0 > c1 ? c0 : c1;
         }
     }
+    // the 64 rows of a wavefront lie in one 4096-row block (kBlock divides 4096): one atomic per wavefront, not per row
 #pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) mine += __shfl_down(mine, o, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0 && mine) atomicAdd(long_nnz, mine);
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mine += __shfl_down(mine, o, kWave);
+        const int a = __shfl_down(lo, o, kWave), b = __shfl_down(hi, o, kWave);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (mine) atomicAdd(long_nnz, mine);
+        if (hi >= 0) {
+            const int64_t r_first = r;   // lane 0's row
+            atomicMin(&bmin[r_first >> 12], lo);
+            atomicMax(&bmax[r_first >> 12], hi);
+        }
+    }
 }
 // ... and lines = an estimate of the distinct lines of x the blocks touch: S (1 - exp(-n / S)) for a block of n nonzeros
 // whose short rows span S lines (what n uniform draws from S lines occupy)
