@@ -93,6 +93,11 @@ def parse():
                     help="column law: >0 = diagonal band of that many columns (default 8192), 0 = uniform random")
     ap.add_argument("--no-extras", action="store_true", help="skip the other column laws / configs (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vendor", default=os.environ.get("SPMV_BENCH_VENDOR", "if-ready"), choices=["if-ready", "wait", "off"],
+                    help="rocSPARSE's best algorithm beside every workload of other_workloads: librocsparse.so (0.5 GB) is "
+                         "loaded by a background thread from the start of the run; 'if-ready' (default) uses it for the workloads "
+                         "that begin after it has loaded and never waits -- on a freshly booted box the load alone takes "
+                         "minutes --, 'wait' waits for it (profiles/r03_bench_n1_full.json), 'off' skips it")
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 23)
     ap.add_argument("--rows-per-gpu", type=int, default=16 << 20, help="N>1: rows of each rank's block (default 16Mi)")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SPMV_BENCH_PIPELINE", "4")),
@@ -103,6 +108,10 @@ def parse():
     ap.add_argument("--total-blocks", type=int, default=32, help="--scaling strong: row blocks of the fixed matrix")
     ap.add_argument("--exchange", default=os.environ.get("SPMV_BENCH_EXCHANGE", "allgather"), choices=["allgather", "p2p"],
                     help="N>1: concatenate y with RCCL's all-gather (default) or with one direct send/recv pair per peer")
+    ap.add_argument("--footprint", action="store_true",
+                    help="N>1, --backend native --exchange p2p only: the optional footprint exchange of include/spmv_dist.h -- every "
+                         "rank receives only the rows of y its own columns reference (a band of 8192: 4096 rows either side of each "
+                         "of its blocks) instead of all of y.  NOT the north-star's all-gather: the line says so")
     ap.add_argument("--backend", default=os.environ.get("SPMV_BENCH_BACKEND", "nccl"),
                     help="nccl (= RCCL through torch.distributed, default) | native (RCCL called from C++: libspmv_dist.so's "
                          "pipelined step, include/spmv_dist.h; torch.distributed/gloo only carries the id, the barrier and the "
@@ -129,6 +138,20 @@ def main():
     capi, W = pkg.capi, pkg.workloads
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: libspmv_hip has no CPU path")
+    # rocSPARSE for the comparison fields: dlopen of the 0.5 GB library in the background, used only once it is there
+    vendor_box = {}
+    if rank == 0 and world == 1 and args.vendor != "off" and not args.no_extras:
+        import threading
+
+        def _load_vendor():
+            try:
+                import ctypes
+                ctypes.CDLL("/opt/rocm/lib/librocsparse.so")
+                vendor_box["loaded"] = True
+            except Exception as ex:
+                vendor_box["error"] = str(ex)[:100]
+        vendor_thread = threading.Thread(target=_load_vendor, daemon=True)
+        vendor_thread.start()
     ndev = torch.cuda.device_count()
     native = args.backend == "native"
     dev_index = local_rank if args.backend in ("nccl", "native") else local_rank % max(ndev, 1)
@@ -232,6 +255,17 @@ def main():
                 dist.broadcast(idt, src=0)
             sh = pkg.dist_native.NativePipeline(world, rank, bytes(idt.numpy().tobytes()), S, sub_rows, w.cols, handles, variant, dev,
                                                 exchange=args.exchange)
+            if args.footprint:
+                if args.exchange != "p2p":
+                    raise SystemExit("--footprint needs --exchange p2p")
+                mine = torch.tensor([[lo if hi >= 0 else 0, hi + 1 if hi >= 0 else 0] for lo, hi in (h.column_range() for h in handles)],
+                                    dtype=torch.int64)
+                every = [torch.zeros_like(mine) for _ in range(world)]
+                if world > 1:
+                    dist.all_gather(every, mine)
+                else:
+                    every = [mine]
+                sh.set_footprint([[int(v) for v in t[:, 0]] for t in every], [[int(v) for v in t[:, 1]] for t in every])
         else:
             sh = pkg.dist.PipelinedSpmv(S, sub_rows, w.cols, [bind(h) for h in handles], dev, exchange=args.exchange)
         if rank == 0:
@@ -352,7 +386,9 @@ def main():
                        f"{S} block-cyclic row blocks per rank x{world} ranks, all-gather(y) of group s "
                        f"({'RCCL all_gather' if args.exchange == 'allgather' else 'direct send/recv per peer'}) "
                        f"overlapped with the multiply of block s+1, "
-                       f"{'RCCL called from C++ (libspmv_dist.so: spmv_dist_pipe_step)' if native else args.backend}",
+                       f"{'RCCL called from C++ (libspmv_dist.so: spmv_dist_pipe_step)' if native else args.backend}"
+                       + (" -- FOOTPRINT exchange: every rank receives only the rows of y its columns reference, not the "
+                          "all-gather of the north-star" if args.footprint else ""),
                        "devices": (f"{world} ranks on {min(world, max(ndev, 1))} device(s)" +
                                    ("" if ndev >= world and args.backend in ("nccl", "native") else
                                     " -- RANKS SHARE DEVICES: a rehearsal of the plumbing, not a scaling measurement")),
@@ -433,16 +469,28 @@ def main():
         # rocSPARSE beside every workload (the reference's vendor slot, cublas.cu:33, is a comparison there too); the
         # library is part of the ROCm image -- when it does not load the fields are simply absent
         rocs, vendor = None, None
-        try:
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("vendor_compare", ROOT / "tools" / "vendor_compare.py")
-            vendor = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(vendor)
-            rocs = vendor.RocSparse()
-            import ctypes
-            rocs._ok(rocs.L.rocsparse_set_stream(rocs.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "set_stream")
-        except Exception:
-            rocs = None
+
+        def vendor_ready():
+            """The rocSPARSE handle once the background load has finished (created here, on the thread that owns the stream)."""
+            nonlocal rocs, vendor
+            if rocs is not None or args.vendor == "off" or "error" in vendor_box:
+                return rocs
+            if args.vendor == "wait":
+                vendor_thread.join()
+            if not vendor_box.get("loaded"):
+                return None
+            try:
+                import ctypes
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("vendor_compare", ROOT / "tools" / "vendor_compare.py")
+                vendor = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(vendor)
+                rocs = vendor.RocSparse()
+                rocs._ok(rocs.L.rocsparse_set_stream(rocs.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "set_stream")
+            except Exception as ex:
+                vendor_box["error"] = str(ex)[:100]
+                rocs = None
+            return rocs
         todo = [("c4", 0), ("c4", 2048), ("c4", 65536), ("c4", 200000), ("c4", 1000000), ("c2", 0), ("c2", 8192), ("c3", 0),
                 ("c3", 8192), ("c5", 8192), ("c5", 0)]
         print(f"[bench] cpu baseline done at {time.perf_counter() - t_main:.1f} s", file=sys.stderr, flush=True)
@@ -471,22 +519,24 @@ def main():
             capi.synth_x(we.seed, 0, we.cols, e_x)
             Ae = capi.CsrMatrix.from_device(n_loc, we.cols, e_rp, e_ci, e_va)
             be = W.algorithmic_bytes(n_loc, we.cols, nnz_e)
-            # every variant timed the same way: warm launches, then the best of three groups of 20; SPMV_AUTO last, so
-            # that it meets clocks and caches in the state its resolved variant met (round 2: "auto" ran first and read
-            # up to 3.5 % slower than the variant it resolves to)
+            # (round 2: "auto" ran first, cold, and read up to 3.5 % slower than the variant it resolves to)
             def timed(v, iters=20, groups=3):
                 Ae.plan(v)
                 Ae.time(v, e_x, e_y, 10)
                 return min(Ae.time(v, e_x, e_y, iters) for _ in range(groups))
-            best, auto = None, None
+            # the variants take turns, three rounds of 20 launches each after a warm round, and keep their best: every one
+            # meets the clocks and caches in the same states
+            names = ("adaptive", "tiled") + (("panel",) if band == 0 else ()) + ("auto",)
             times = {}
-            for vn in ("adaptive", "tiled") + (("panel",) if band == 0 else ()) + ("auto",):
-                ms = timed(capi.VARIANTS[vn])
-                times[vn] = ms
-                if vn == "auto":
-                    auto = (Ae.plan_describe(capi.VARIANTS[vn]), ms)
-                if best is None or ms < best[1]:
-                    best = (vn, ms)
+            for vn in names:
+                Ae.plan(capi.VARIANTS[vn])
+                Ae.time(capi.VARIANTS[vn], e_x, e_y, 10)
+            for _round in range(3):
+                for vn in names:
+                    ms = Ae.time(capi.VARIANTS[vn], e_x, e_y, 20)
+                    times[vn] = min(times.get(vn, ms), ms)
+            best = min(times.items(), key=lambda kv: kv[1])
+            auto = (Ae.plan_describe(capi.VARIANTS["auto"]), times["auto"])
             auto_plan = auto[0]
             resolved = auto_plan.split("auto -> ")[1].split(":")[0] if "auto -> " in auto_plan else "auto"
             # the kernel BASELINE.json's config string names for this config, timed beside the library's choice
@@ -509,7 +559,7 @@ def main():
                      **({"config_named_kernel": named_out} if named_out else {})}
             if resolved == "tiled" and resolved in times:
                 entry["resolved_variant_kernel_ms"] = round(times[resolved], 5)   # the same plan timed under its own name
-            if rocs is not None:
+            if vendor_ready() is not None:
                 try:
                     # (the two algorithms that were rocSPARSE's best on every workload of rounds 1 and 2; all four are in
                     # tools/vendor_compare.py -> profiles/r02_vendor_compare.jsonl)
@@ -552,7 +602,7 @@ def main():
               "best_variant": best[0], "best_kernel_ms": round(best[1], 5),
               "best_frac_of_peak": round(b3 / best[1] / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": b3,
               **honest_fields(b3, auto[1], len(ci3), N3, touched_x_bytes(torch, t_ci, N3), auto[0], None)}
-        if rocs is not None:
+        if vendor_ready() is not None:
             try:
                 rt = vendor.rocsparse_times(rocs, N3, N3, len(ci3), t_rp, t_ci, t_va, t_x, t_y, iters=10,
                                             algs={k: vendor.ALGS[k] for k in ("csr_adaptive", "csr_nnzsplit")})
@@ -566,6 +616,10 @@ def main():
         extras.append(e3)
         A3.close()
         out["other_workloads"] = extras
+        out["vendor_comparison"] = ("rocSPARSE (csr_adaptive, csr_nnzsplit: its best on every workload of rounds 1-2) timed beside "
+                                    f"{sum(1 for e in extras if 'rocsparse_best_ms' in e)} of {len(extras)} workloads; --vendor {args.vendor}"
+                                    + (": " + vendor_box["error"] if "error" in vendor_box else "")
+                                    + ("" if vendor_box.get("loaded") else ": librocsparse.so had not finished loading (run with --vendor wait)"))
         # the headline's config under the other column laws, next to the headline (BASELINE fixes c4's sizes and
         # row-length law, not its column law: the value above holds for the law named in config.workload only)
         laws = {f"band {args.band}" if args.band else "uniform": round(achieved / HBM_PEAK_GBS, 4)}

@@ -91,6 +91,17 @@ SPMV_API int spmv_dist_pipe_step(spmv_dist_pipe_t *p, spmv_csr_t *const *blocks,
                                  void *stream);
 /* The S exchanges of one step without the products (what the exchange alone costs). */
 SPMV_API int spmv_dist_pipe_exchange_only(spmv_dist_pipe_t *p, float *d_y_full, void *stream);
+/* Footprint exchange (optional; the default concatenates all of y on every rank, which is what the north-star fixes).
+ * A rank's blocks reference only some columns of x; where y becomes the next x (an iteration), rank q needs y only on its
+ * own column footprint -- for a band of 8192 columns that is each of its blocks' rows plus 4096 on either side instead of
+ * the other ranks' 7 x 64 MiB.  A rank's footprint is given as `per_rank` intervals (one per block: the blocks of a rank
+ * lie world blocks apart, one interval around all of them would span nearly everything): rank q needs rows
+ * [need_lo[q*per_rank + k], need_hi[q*per_rank + k]), k = 0..per_rank-1.  After this call the exchanges of SPMV_DIST_P2P and
+ * SPMV_DIST_PEER_STORE pipes move, from every owner to every peer, only the rows of the group's slot that fall inside one of
+ * the PEER's intervals (nothing where they do not meet); y_full is then complete on a rank inside its footprint and on its
+ * own rows only.  The arrays must be the same on every rank (spmv_csr_column_range of every block, all-gathered by the
+ * caller).  Not for SPMV_DIST_ALLGATHER. */
+SPMV_API int spmv_dist_pipe_set_footprint(spmv_dist_pipe_t *p, const int64_t *need_lo, const int64_t *need_hi, int per_rank);
 SPMV_API int spmv_dist_pipe_finish(spmv_dist_pipe_t *p, void *stream);
 SPMV_API int spmv_dist_pipe_destroy(spmv_dist_pipe_t *p);
 

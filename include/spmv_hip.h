@@ -129,6 +129,11 @@ SPMV_API int spmv_csr_download(const spmv_csr_t *h, int32_t *row_ptr, int32_t *c
 SPMV_API int spmv_csr_validate(const spmv_csr_t *h, void *stream);
 
 SPMV_API int spmv_csr_dims(const spmv_csr_t *h, int64_t *rows, int64_t *cols, int64_t *nnz);
+
+/* The smallest and the largest column index the matrix references (one device pass over col_idx, synchronous):
+ * *col_min = cols, *col_max = -1 for a matrix without nonzeros.  A row block's x footprint -- what a sharded multiply has
+ * to make available to the rank that holds it (include/spmv_dist.h: spmv_dist_pipe_set_footprint). */
+SPMV_API int spmv_csr_column_range(const spmv_csr_t *h, int64_t *col_min, int64_t *col_max, void *stream);
 SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
 
 /* ---- the hot path ------------------------------------------------------

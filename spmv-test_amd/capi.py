@@ -42,6 +42,7 @@ SIGNATURES = {
     "spmv_csr_download": (C.c_int, [_H, _i32p, _i32p, _f32p]),
     "spmv_csr_validate": (C.c_int, [_H, C.c_void_p]),
     "spmv_csr_dims": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "spmv_csr_column_range": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]),
     "spmv_csr_destroy": (C.c_int, [_H]),
     "spmv_csr_plan": (C.c_int, [_H, C.c_int, _vp]),
     "spmv_csr_run": (C.c_int, [_H, C.c_int, _f32p, _f32p, _vp]),
@@ -192,6 +193,12 @@ class CsrMatrix:
         """Enqueue y = A x on torch's current stream (or ``stream``).  x, y: float32 device tensors."""
         assert x.numel() >= self.cols and y.numel() >= self.rows
         check(lib().spmv_csr_run(self._h, variant, _ptr(x), _ptr(y), _stream_handle(stream)))
+
+    def column_range(self, stream=None):
+        """(smallest, largest) column index referenced; (cols, -1) for a matrix without nonzeros."""
+        lo, hi = C.c_int64(), C.c_int64()
+        check(lib().spmv_csr_column_range(self._h, C.byref(lo), C.byref(hi), _stream_handle(stream)))
+        return lo.value, hi.value
 
     def values_changed(self) -> None:
         """The caller rewrote vals (borrowed arrays): plans that hold a copy of them are stale from here on."""

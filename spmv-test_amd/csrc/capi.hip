@@ -271,6 +271,22 @@ int spmv_csr_dims(const spmv_csr_t *h, int64_t *rows, int64_t *cols, int64_t *nn
     return SPMV_OK;
 }
 
+int spmv_csr_column_range(const spmv_csr_t *h, int64_t *col_min, int64_t *col_max, void *stream)
+{
+    if (!h || !col_min || !col_max) { set_error("spmv_csr_column_range: null argument"); return SPMV_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    DevPtr<int32_t> d;
+    SPMV_HIP_TRY(d.alloc(2));
+    int rc = launch_column_range(*h, d.p, st);
+    if (rc) return rc;
+    int32_t out[2] = {0, 0};
+    SPMV_HIP_TRY(hipMemcpyAsync(out, d.p, sizeof out, hipMemcpyDeviceToHost, st));
+    SPMV_HIP_TRY(hipStreamSynchronize(st));
+    *col_min = out[1] < 0 ? h->cols : (int64_t)out[0];
+    *col_max = (int64_t)out[1];
+    return SPMV_OK;
+}
+
 int spmv_csr_destroy(spmv_csr_t *h)
 {
     if (!h) return SPMV_OK;

@@ -402,6 +402,42 @@ int launch_validate(const spmv_csr *h, int32_t *d_bad4, hipStream_t stream)
 }
 
 // ---------------------------------------------------------------------------
+// spmv_csr_column_range: grid-stride min / max over col_idx
+__global__ __launch_bounds__(256) void k_column_range(int64_t nnz, const int32_t *__restrict__ col_idx, int32_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int mn = 0x7fffffff, mx = -1;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) {
+        const int c = col_idx[k];
+        mn = c < mn ? c : mn;
+        mx = c > mx ? c : mx;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const int a = __shfl_down(mn, o, kWave), b = __shfl_down(mx, o, kWave);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && mx >= 0) {
+        atomicMin(&out[0], mn);
+        atomicMax(&out[1], mx);
+    }
+}
+
+int launch_column_range(const spmv_csr &h, int32_t *d_out2, hipStream_t s)
+{
+    const int32_t init[2] = {0x7fffffff, -1};
+    SPMV_HIP_TRY(hipMemcpyAsync(d_out2, init, sizeof init, hipMemcpyHostToDevice, s));
+    if (h.nnz > 0) {
+        int64_t blocks = (h.nnz + 256 * 16 - 1) / (256 * 16);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        k_column_range<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(h.nnz, h.d_col_idx, d_out2);
+        return check_launch("k_column_range");
+    }
+    return SPMV_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Checksum of vals for the stale-plan guard (SPMV_CHECK_VALUES=1): position-mixed, so a permutation changes it too.
 __global__ __launch_bounds__(256) void k_values_checksum(int64_t nnz, const float *__restrict__ vals,
                                                          unsigned long long *__restrict__ out)

@@ -217,6 +217,8 @@ bool check_values_env();   // SPMV_CHECK_VALUES=1 (read once)
 // stamp a plan that has just copied vals / refuse to run one whose copy is out of date (SPMV_ERR_STALE_PLAN)
 int stamp_values(const spmv_csr &h, hipStream_t s, ValuesStamp &st);
 int require_fresh_values(const spmv_csr &h, const ValuesStamp &st, hipStream_t s, const char *variant);
+// min / max of col_idx (kernels_rows.hip): d_out[0] = min (INT_MAX when nnz = 0), d_out[1] = max (-1)
+int launch_column_range(const spmv_csr &h, int32_t *d_out2, hipStream_t s);
 // in-place exclusive scan of n int32 (one 1024-thread workgroup); the total goes to *d_total
 int exclusive_scan_i32(int32_t *d_data, int64_t n, int32_t *d_total, hipStream_t s);
 

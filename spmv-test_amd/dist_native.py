@@ -38,6 +38,7 @@ SIGNATURES = {
     "spmv_dist_pipe_link": (C.c_int, [_PP, _PP, C.c_int]),
     "spmv_dist_pipe_step": (C.c_int, [_vp, _PP, C.c_int, _vp, _vp, _vp]),
     "spmv_dist_pipe_exchange_only": (C.c_int, [_vp, _vp, _vp]),
+    "spmv_dist_pipe_set_footprint": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
     "spmv_dist_pipe_finish": (C.c_int, [_vp, _vp]),
     "spmv_dist_pipe_destroy": (C.c_int, [_vp]),
 }
@@ -105,6 +106,15 @@ class NativePipeline:
 
     def broadcast_x(self, src: int = 0) -> None:
         check(lib().spmv_dist_broadcast_x(self._d, self.x.data_ptr(), src, capi._stream_handle()))
+
+    def set_footprint(self, need_lo, need_hi) -> None:
+        """The optional footprint exchange: ``need_lo/need_hi[q][k]`` = rows of y rank q's k-th block references (the same
+        lists on every rank); 'p2p' only."""
+        per_rank = len(need_lo[0])
+        flat_lo = [int(v) for row in need_lo for v in row]
+        flat_hi = [int(v) for row in need_hi for v in row]
+        n = len(flat_lo)
+        check(lib().spmv_dist_pipe_set_footprint(self._p, (C.c_int64 * n)(*flat_lo), (C.c_int64 * n)(*flat_hi), per_rank))
 
     def step(self):
         check(lib().spmv_dist_pipe_step(self._p, self._blocks, self.variant, self.x.data_ptr(), self.y_full.data_ptr(),

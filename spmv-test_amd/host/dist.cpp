@@ -34,6 +34,9 @@ struct spmv_dist_pipe {
     // PEER_STORE (spmv_dist_pipe_link): every rank's pipe and y_full, index = rank
     std::vector<spmv_dist_pipe *> peers;
     std::vector<float *> peer_y;
+    // footprint exchange (spmv_dist_pipe_set_footprint): rank q needs the rows of need_k intervals of y; none set = everything
+    std::vector<int64_t> need_lo, need_hi;   // [world * need_k]
+    int need_k = 0;
 };
 
 namespace {
@@ -307,7 +310,35 @@ int spmv_dist_pipe_link(spmv_dist_pipe_t *const *pipes, float *const *d_y_full, 
     return SPMV_OK;
 }
 
+int spmv_dist_pipe_set_footprint(spmv_dist_pipe_t *p, const int64_t *need_lo, const int64_t *need_hi, int per_rank)
+{
+    if (!p || !need_lo || !need_hi || per_rank < 1 || per_rank > 4096) return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_set_footprint: bad argument");
+    if (p->exchange == SPMV_DIST_ALLGATHER)
+        return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_set_footprint: an all-gather moves whole slices (use SPMV_DIST_P2P or SPMV_DIST_PEER_STORE)");
+    const int n = p->d->world * per_rank;
+    for (int i = 0; i < n; ++i)
+        if (need_lo[i] < 0 || need_hi[i] < need_lo[i]) return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_set_footprint: bad interval %d", i);
+    p->need_lo.assign(need_lo, need_lo + n);
+    p->need_hi.assign(need_hi, need_hi + n);
+    p->need_k = per_rank;
+    return SPMV_OK;
+}
+
 namespace {
+
+// how many parts of rank `owner`'s slot of group s rank `peer` needs (1 = the whole slot, without a footprint), and part k
+inline int needed_parts(const spmv_dist_pipe *p) { return p->need_k > 0 ? p->need_k : 1; }
+inline void needed_part(const spmv_dist_pipe *p, int s, int owner, int peer, int k, int64_t *a, int64_t *b)
+{
+    const int64_t r0 = ((int64_t)s * p->d->world + owner) * p->sub_rows, r1 = r0 + p->sub_rows;
+    *a = r0;
+    *b = r1;
+    if (p->need_k == 0) return;
+    const int64_t lo = p->need_lo[(size_t)peer * p->need_k + k], hi = p->need_hi[(size_t)peer * p->need_k + k];
+    if (lo > *a) *a = lo;
+    if (hi < *b) *b = hi;
+    if (*b < *a) *b = *a;
+}
 
 // the exchange of block group s on the pipe's side stream (which already waits for whatever must come first)
 int exchange_group(spmv_dist_pipe *p, int s, float *d_y_full)
@@ -326,8 +357,17 @@ int exchange_group(spmv_dist_pipe *p, int s, float *d_y_full)
             DIST_NCCL(ncclGroupStart());
             for (int q = 0; q < world; ++q) {
                 if (q == d->rank) continue;
-                ncclResult_t e = ncclSend(mine, n, ncclFloat, q, d->comm, p->comm);
-                if (e == ncclSuccess) e = ncclRecv(grp + (int64_t)q * p->sub_rows, n, ncclFloat, q, d->comm, p->comm);
+                // what q needs of my slot goes out, what I need of q's slot comes in: both sides compute both ranges from the
+                // same footprints, so the send and the receive of a pair agree in size (and are both skipped when empty)
+                // (a row inside two of a rank's intervals -- a band wider than a block -- travels twice: harmless, and both sides agree)
+                ncclResult_t e = ncclSuccess;
+                for (int k = 0; k < needed_parts(p) && e == ncclSuccess; ++k) {
+                    int64_t sa, sb, ra, rb;
+                    needed_part(p, s, d->rank, q, k, &sa, &sb);
+                    needed_part(p, s, q, d->rank, k, &ra, &rb);
+                    if (sb > sa) e = ncclSend(d_y_full + sa, (size_t)(sb - sa), ncclFloat, q, d->comm, p->comm);
+                    if (e == ncclSuccess && rb > ra) e = ncclRecv(d_y_full + ra, (size_t)(rb - ra), ncclFloat, q, d->comm, p->comm);
+                }
                 if (e != ncclSuccess) { (void)ncclGroupEnd(); return fail(SPMV_ERR_HIP, "ncclSend/ncclRecv(peer %d): %s", q, ncclGetErrorString(e)); }
             }
             DIST_NCCL(ncclGroupEnd());
@@ -336,10 +376,15 @@ int exchange_group(spmv_dist_pipe *p, int s, float *d_y_full)
         default: {                     // PEER_STORE: my slice into the same place of every peer's y_full
             if ((int)p->peers.size() != world) return fail(SPMV_ERR_INVALID, "SPMV_DIST_PEER_STORE: spmv_dist_pipe_link has not been called");
             if (p->peer_y[d->rank] != d_y_full) return fail(SPMV_ERR_INVALID, "SPMV_DIST_PEER_STORE: y_full differs from the linked buffer");
-            const int64_t off = mine - d_y_full;
             for (int k = 1; k < world; ++k) {   // start with the next rank: the owners do not all hit one peer at once
                 const int q = (d->rank + k) % world;
-                DIST_HIP(hipMemcpyPeerAsync(p->peer_y[q] + off, p->peers[q]->d->device, mine, d->device, n * sizeof(float), p->comm));
+                for (int k = 0; k < needed_parts(p); ++k) {
+                    int64_t a, b;
+                    needed_part(p, s, d->rank, q, k, &a, &b);   // (the whole slot without a footprint)
+                    if (b > a)
+                        DIST_HIP(hipMemcpyPeerAsync(p->peer_y[q] + a, p->peers[q]->d->device, d_y_full + a, d->device,
+                                                    (size_t)(b - a) * sizeof(float), p->comm));
+                }
             }
             return SPMV_OK;
         }

@@ -3,13 +3,14 @@
 // matrix multiplied by a single handle.  Also the worked example of INTEGRATION.md for a C++ caller.
 //
 //   spmv_dist_selftest [--ranks N] [--rows-per-rank R] [--band B] [--unequal] [--variant tiled|adaptive|scalar|auto] [--steps K]
-//                      [--pipeline S] [--exchange allgather|p2p|peer] [--local]
+//                      [--pipeline S] [--exchange allgather|p2p|peer] [--local] [--footprint]
 // N defaults to the number of visible GPUs.  Matrix: (N*R)^2, 16 nonzeros per row (config 2's law), generated on
 // the devices by spmv_synth_fill; with --unequal the blocks hold R-17, R+17, ... rows (the all-gather-v path).
 // --pipeline S (round 3): the pipelined step of spmv_dist.h -- every rank's R rows as S block-cyclic blocks, the exchange
 // of block group s on a side stream under the multiply of block s+1 -- with RCCL's all-gather, a grouped send/recv pair per
 // peer, or peer stores (hipMemcpyPeerAsync, no RCCL).  --local: ranks without a communicator (spmv_dist_init_local), as
 // many as asked on the visible devices round-robin -- the whole pipeline with world > 1 on a ONE-GPU box (peer stores only).
+// --footprint: the optional footprint exchange -- every rank receives only the rows of y its own columns reference.
 // Prints one JSON line; exit code 0 iff every rank's y is bit-identical to the single-handle result.
 #include <hip/hip_runtime.h>
 
@@ -47,13 +48,13 @@ struct Rank {
     spmv_dist_pipe_t *pipe = nullptr;
 };
 
-static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local);
+static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint);
 
 int main(int argc, char **argv)
 {
     int ndev = spmv_device_count();
     int64_t per = 1 << 18, band = 4096;
-    bool unequal = false, local = false;
+    bool unequal = false, local = false, footprint = false;
     int variant = SPMV_TILED, steps = 20, pipeline = 0, exchange = SPMV_DIST_ALLGATHER;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -64,6 +65,7 @@ int main(int argc, char **argv)
         else if (a == "--steps") steps = atoi(next());
         else if (a == "--unequal") unequal = true;
         else if (a == "--local") local = true;
+        else if (a == "--footprint") footprint = true;
         else if (a == "--pipeline") pipeline = atoi(next());
         else if (a == "--exchange") {
             std::string v = next();
@@ -79,7 +81,7 @@ int main(int argc, char **argv)
     }
     if (ndev < 1 || (!local && ndev > spmv_device_count())) { fprintf(stderr, "HIP error: %d ranks asked, %d devices visible\n", ndev, spmv_device_count()); return EXIT_FAILURE; }
     if (local && spmv_device_count() < 1) { fprintf(stderr, "HIP error: no device visible\n"); return EXIT_FAILURE; }
-    if (pipeline > 0) return run_pipeline(ndev, per, band, variant, steps, pipeline, exchange, local);
+    if (pipeline > 0) return run_pipeline(ndev, per, band, variant, steps, pipeline, exchange, local, footprint);
     if (local) { fprintf(stderr, "--local needs --pipeline S --exchange peer\n"); return 2; }
     const uint64_t seed = 20251031;
     const int64_t rows = per * ndev, cols = rows;
@@ -217,8 +219,9 @@ int main(int argc, char **argv)
 
 
 // ---- the pipelined step: S block-cyclic blocks per rank, exchange of group s under the multiply of block s+1 ------------
-static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local)
+static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint)
 {
+    if (footprint && exchange == SPMV_DIST_ALLGATHER) { fprintf(stderr, "--footprint needs --exchange p2p or peer\n"); return 2; }
     if (S < 1 || per % S) { fprintf(stderr, "--rows-per-rank must be a multiple of --pipeline\n"); return 2; }
     if (local && exchange != SPMV_DIST_PEER_STORE) { fprintf(stderr, "--local ranks exchange by peer stores only (--exchange peer)\n"); return 2; }
     const uint64_t seed = 20251031;
@@ -277,6 +280,21 @@ static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int st
         for (int r = 0; r < ndev; ++r) { pipes[r] = rk[r].pipe; ys[r] = rk[r].d_y; }
         OK_SPMV(spmv_dist_pipe_link(pipes.data(), ys.data(), ndev));
     }
+    // --footprint: every rank's column footprint (spmv_csr_column_range over its blocks), known to all, set on every pipe:
+    // the exchanges then move only what the receiving rank's columns reference
+    std::vector<int64_t> need_lo((size_t)ndev * S, 0), need_hi((size_t)ndev * S, rows);
+    if (footprint) {
+        for (int r = 0; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            for (int s = 0; s < S; ++s) {       // one interval per block: a rank's blocks lie world blocks apart
+                int64_t a, b;
+                OK_SPMV(spmv_csr_column_range(rk[r].blocks[s], &a, &b, rk[r].stream));
+                need_lo[(size_t)r * S + s] = b < 0 ? 0 : a;
+                need_hi[(size_t)r * S + s] = b < 0 ? 0 : b + 1;
+            }
+        }
+        for (int r = 0; r < ndev; ++r) OK_SPMV(spmv_dist_pipe_set_footprint(rk[r].pipe, need_lo.data(), need_hi.data(), S));
+    }
     // every block planned like rank 0's first
     int32_t params[8];
     OK_HIP(hipSetDevice(rk[0].device));
@@ -324,11 +342,18 @@ static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int st
     OK_HIP(hipStreamSynchronize(rk[0].stream));
     std::vector<float> yref(rows), y(rows);
     OK_HIP(hipMemcpy(yref.data(), d_yref, sizeof(float) * rows, hipMemcpyDeviceToHost));
-    int64_t differing = 0;
+    int64_t differing = 0, untouched = 0;
     for (int r = 0; r < ndev; ++r) {
         OK_HIP(hipSetDevice(rk[r].device));
         OK_HIP(hipMemcpy(y.data(), rk[r].d_y, sizeof(float) * rows, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < rows; ++i) differing += std::memcmp(&y[i], &yref[i], sizeof(float)) != 0;
+        for (int64_t i = 0; i < rows; ++i) {
+            // with a footprint a rank holds y on its own rows and inside its footprint; the rest keeps the NaN it was preset to
+            const bool own = (i / sub) % ndev == r;
+            bool needed = !footprint || own;
+            for (int s = 0; s < S && !needed; ++s) needed = i >= need_lo[(size_t)r * S + s] && i < need_hi[(size_t)r * S + s];
+            if (needed) differing += std::memcmp(&y[i], &yref[i], sizeof(float)) != 0;
+            else untouched += y[i] != y[i];
+        }
     }
 
     hipEvent_t e0, e1;
@@ -367,11 +392,12 @@ static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int st
     const double bytes = 8.0 * nnz_all + 4.0 * (rows + (double)ndev * S) + 4.0 * rows + 4.0 * cols * ndev;
     const char *xname = exchange == SPMV_DIST_ALLGATHER ? "allgather" : exchange == SPMV_DIST_P2P ? "p2p" : "peer";
     printf("{\"world\": %d, \"process_model\": \"%s\", \"pipeline_blocks_per_rank\": %d, \"exchange\": \"%s\", \"rows\": %lld, "
-           "\"nnz\": %lld, \"band\": %lld, \"variant\": \"%s\", \"rows_differing_from_single_handle\": %lld, \"step_ms\": %.5f, "
+           "\"nnz\": %lld, \"band\": %lld, \"variant\": \"%s\", \"footprint_exchange\": %s, \"rows_never_sent_to_a_rank_that_does_not_need_them\": %lld, "
+           "\"rows_differing_from_single_handle\": %lld, \"step_ms\": %.5f, "
            "\"multiply_only_ms\": %.5f, \"exchange_only_ms\": %.5f, \"aggregate_GBs\": %.1f, \"plan\": \"%s\"}\n",
            ndev, local ? "one process, local ranks (no communicator), devices round-robin" : "one process, ncclCommInitAll", S, xname,
-           (long long)rows, (long long)nnz_all, (long long)band, spmv_variant_name(variant), (long long)differing, step_ms, mult_ms,
-           xchg_ms, bytes / (step_ms * 1e-3) / 1e9, plan);
+           (long long)rows, (long long)nnz_all, (long long)band, spmv_variant_name(variant), footprint ? "true" : "false",
+           (long long)untouched, (long long)differing, step_ms, mult_ms, xchg_ms, bytes / (step_ms * 1e-3) / 1e9, plan);
     for (int r = 0; r < ndev; ++r) {
         OK_HIP(hipSetDevice(rk[r].device));
         (void)spmv_dist_pipe_destroy(rk[r].pipe);

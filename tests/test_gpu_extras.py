@@ -8,7 +8,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from _util import assert_close_to_oracle, synth_problem
+from _util import DeviceProblem, assert_close_to_oracle, synth_problem
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
@@ -273,7 +273,9 @@ def test_dist_selftest_world_of_one_gpu(pkg, gpu):
     ["--local", "--ranks", "3", "--pipeline", "2", "--exchange", "peer", "--variant", "adaptive", "--band", "200000"],
     ["--local", "--ranks", "2", "--pipeline", "1", "--exchange", "peer", "--variant", "auto", "--band", "200000",
      "--rows-per-rank", str(1 << 20)],
-], ids=["allgather", "p2p-auto", "peer-4ranks", "peer-3ranks", "peer-sorted-blocks"])
+    ["--local", "--ranks", "4", "--pipeline", "4", "--exchange", "peer", "--footprint", "--band", "8192"],   # the optional footprint exchange
+    ["--pipeline", "2", "--exchange", "p2p", "--footprint"],
+], ids=["allgather", "p2p-auto", "peer-4ranks", "peer-3ranks", "peer-sorted-blocks", "peer-footprint", "p2p-footprint"])
 def test_dist_pipeline_selftest(pkg, gpu, args):
     """The pipelined step of include/spmv_dist.h from C++: S block-cyclic row blocks per rank, the
     exchange of block group s on a side stream under the multiply of block s+1, three steps back to back, every rank's y
@@ -294,3 +296,20 @@ def test_dist_pipeline_selftest(pkg, gpu, args):
     assert out["rows_differing_from_single_handle"] == 0 and out["step_ms"] > 0
     if "--local" in args:
         assert out["world"] == int(args[args.index("--ranks") + 1]) and out["exchange"] == "peer"
+    if "--footprint" in args and out["world"] > 1:
+        # a band of 8192 columns: a rank's footprint is its own rows plus 4096 on either side of each of its blocks --
+        # most of y is never sent to it (those rows keep the NaN they were preset to)
+        assert out["footprint_exchange"] is True
+        assert out["rows_never_sent_to_a_rank_that_does_not_need_them"] > 0
+
+
+def test_column_range(pkg, gpu):
+    """spmv_csr_column_range: a row block's x footprint (what the footprint exchange of spmv_dist.h is set up with)."""
+    capi = pkg.capi
+    rp = np.array([0, 2, 2, 5], np.int32); ci = np.array([7, 3, 11, 4, 9], np.int32); va = np.ones(5, np.float32)
+    prob = DeviceProblem(pkg, gpu, 3, 20, rp, ci, va, np.ones(20, np.float32))
+    assert prob.A.column_range() == (3, 11)
+    prob.A.close()
+    prob = DeviceProblem(pkg, gpu, 2, 20, np.zeros(3, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), np.ones(20, np.float32))
+    assert prob.A.column_range() == (20, -1)
+    prob.A.close()
