@@ -371,8 +371,8 @@ int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream)
     switch (variant) {
         case SPMV_AUTO: return plan_auto(*h, s);
         case SPMV_SCALAR:
-        case SPMV_WAVE:
-        case SPMV_WAVE_PIPE: return SPMV_OK;
+        case SPMV_WAVE: return SPMV_OK;
+        case SPMV_WAVE_PIPE: return plan_wave(*h, s);
         case SPMV_VECTOR: return plan_vector(*h, s);
         case SPMV_ADAPTIVE: return plan_adaptive(*h, false, s);
         case SPMV_TILED: return plan_adaptive(*h, true, s);
@@ -522,6 +522,8 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
             if (panel.sorted_mode)   // unit bases, block tables, the rows of the tail units, the empty slots of the units in use
                 return panel.units * 4 + (int64_t)panel.nblocks * 20 + panel.tail_units * 512;
             return (int64_t)panel.nblocks * (panel.npanels + 1) * 4 + ((int64_t)panel.nblocks + 1) * 4;
+        case SPMV_WAVE_PIPE: // the long rows' list, piece table read, partial sums written and re-read
+            return (int64_t)h->plan_wave.n_long * 8 + (int64_t)h->plan_wave.pieces * 16 + h->plan_wave.blocks * 8;
         default: return 0;
     }
 }
@@ -542,6 +544,11 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
     }
     const ChunkPlan *p = variant == SPMV_ADAPTIVE ? &h->plan_adaptive : (variant == SPMV_TILED ? &h->plan_tiled : nullptr);
     if (variant == SPMV_VECTOR) snprintf(buf, (size_t)n, "lanes_per_row=%d", h->vector_width);
+    else if (variant == SPMV_WAVE_PIPE) {
+        if (!h->plan_wave.ready) snprintf(buf, (size_t)n, "not planned (the first run plans)");
+        else snprintf(buf, (size_t)n, "long_rows=%d pieces=%d blocks=%lld blocks_with_x_window=%lld", h->plan_wave.n_long,
+                      h->plan_wave.pieces, (long long)h->plan_wave.blocks, (long long)h->plan_wave.win_blocks);
+    }
     else if (variant == SPMV_PANEL && panel->ready && panel->sorted_mode)
         snprintf(buf, (size_t)n, "sorted_blocks=%d rows_per_block=%d wavefronts=%d lines_per_nonzero=%.3f tail_nonzeros=%lld wide_blocks=%lld model_cost=%.3f",
                  panel->nblocks, panel->sb_rows, panel->sb_waves,

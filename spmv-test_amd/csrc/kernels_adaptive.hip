@@ -1598,6 +1598,7 @@ void destroy_plans(spmv_csr &h)
     destroy_panel(h.plan_panel);
     destroy_panel(h.plan_auto_panel);
     destroy_xskip(h.plan_xskip);
+    destroy_wave(h.plan_wave);
 }
 
 static int resident_workgroups(int device, int block, int waves_simd)

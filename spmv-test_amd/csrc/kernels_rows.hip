@@ -15,9 +15,17 @@
 //
 // All three are HBM/gather bound: no LDS, no MFMA (0.25 flop/byte).
 #include <cstdlib>
+#include <vector>
 #include "spmv_internal.hpp"
 
 namespace spmv {
+
+// A/B builds (tools/build_variant.sh): what a kernel costs without its gathers / its long rows / its in-order sums
+#ifdef SPMV_R_NOGATHER
+#define XG(c, k) x[((c) & 0) + ((k) & 1023)]
+#else
+#define XG(c, k) x[(c)]
+#endif
 
 // One row by the whole wave IN THE ORACLE'S ORDER: 64 lane-consecutive products per trip (coalesced, each rounded
 // once, the next trip's loads already in flight), then added in order -- lane 0's first -- through a readlane chain.
@@ -78,13 +86,17 @@ __global__ __launch_bounds__(kBlock) void k_scalar(int64_t rows, const int32_t *
     const int32_t b = r < rows ? row_ptr[r] : 0, e = r < rows ? row_ptr[r + 1] : 0;
     if (we - wb <= kScalarCap) {
         for (int32_t k = wb + (int32_t)threadIdx.x; k < we; k += kBlock) {
-            const float p = x[col_idx[k]] * vals[k];
+            const float p = XG(col_idx[k], k) * vals[k];
             prod[k - wb] = p;
         }
         __syncthreads();
         if (r < rows) {
             float acc = 0.0f;
+#ifdef SPMV_R_NOSUM
+            if (e > b) acc = prod[b - wb];
+#else
             for (int32_t k = b; k < e; ++k) acc = acc + prod[k - wb];
+#endif
             y[r] = acc;
         }
     } else {
@@ -179,75 +191,366 @@ __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__
     if (lane == 0) y[r] = acc;
 }
 
-// SPMV_WAVE_PIPE (the slot of wsp_kernel_v1, the reference's unrolled / prefetching version): a wavefront owns 64
-// consecutive rows.  When their nonzeros fit its LDS slice the wave streams the whole contiguous range with
-// coalesced loads (lane-consecutive nonzeros, the whole wave busy whatever the row lengths), parks the products,
-// and every lane then adds the products of ITS row in order; rows longer than a wavefront are added by all 64
-// lanes with the __shfl_down tree instead.  A bundle that does not fit is taken in as many consecutive rows as do; a
-// row that does not fit on its own goes through wave_row<true> (four slices in flight, straight from memory).
-constexpr int kBundleCap = 2048;   // products per wave: 8 KiB of LDS, 32 KiB per workgroup
-__global__ __launch_bounds__(kBlock) void k_wave_bundle(int64_t rows, const int32_t *__restrict__ row_ptr,
-                                                        const int32_t *__restrict__ col_idx,
-                                                        const float *__restrict__ vals,
-                                                        const float *__restrict__ x, float *__restrict__ y)
+// SPMV_WAVE_PIPE (the slot of wsp_kernel_v1, the reference's unrolled / prefetching version, wsp.cu:59-138): a wavefront
+// owns 64 consecutive rows, eight wavefronts (512 rows) make a workgroup.
+//   * Rows of up to kBundleCap nonzeros: the wave takes them in runs of consecutive rows that hold at most kBundleCap
+//     nonzeros together, streams that contiguous range with coalesced loads -- lane-consecutive nonzeros, the whole wave busy
+//     whatever the row lengths, ALL of the run's loads issued before the first use and the next run's loads issued before
+//     this one's sums (the pipelining wsp_kernel_v1 adds to v0, at the depth HBM latency asks of a wave64) -- parks the
+//     products in its LDS slice, and every lane adds the products of ITS row in order; rows longer than a wavefront are
+//     added by all 64 lanes with the __shfl_down tree.
+//   * Longer rows are cut by the plan into pieces of kPieceLen nonzeros for k_wave_pieces: one wavefront per piece wherever
+//     on the chip there is room (one coalesced stream + a wave sum into a word of the plan's scratch); k_wave_combine then
+//     adds a row's pieces in order.
+//   * x comes from a window in LDS -- the entries [lo, lo + kWaveWindow) that hold every column of the block's 512 rows
+//     (the long ones excepted: theirs are gathered from memory), found by the plan -- where such a window exists, else
+//     from memory.
+// The plan is a function of row_ptr and col_idx (not of the values), made by spmv_csr_plan or by the first run.
+// Round 3's A/Bs (profiles/r03_rows_bounds.jsonl; config 3 with band 8192, 0.759 ms before, 0.386 ms now): the longest rows
+// -- 65 536 nonzeros on ONE wavefront, 256 dependent trips -- were 0.40 ms of it; with the streams at full depth (0.16 ms
+// without the gathers) the 4-byte gathers from L2 were 0.34 ms more, at one 128-byte line per lane and instruction: hence
+// the window.  Tried in between and dropped: long rows by their own wave (the other seven wait with the workgroup's LDS), by
+// the workgroup after a barrier with lists and counters in LDS (0.55-0.69 ms: barriers and bookkeeping), a window guessed
+// without a plan from sampled columns (two more round trips in every workgroup), the pieces inside the bundle kernel
+// (0.44 ms: its LDS leaves three workgroups per CU, too few loads in flight for the pieces), a window per long row (the
+// synthetic band law gives a row of n nonzeros 8n columns: as many bytes of windows as of matrix), the pieces on a second
+// stream beside the bundles (no overlap: 0.386 against 0.382 ms).
+#ifndef SPMV_BUNDLE_CAP
+#define SPMV_BUNDLE_CAP 512
+#endif
+constexpr int kBundleCap = SPMV_BUNDLE_CAP;        // products per wave and run (4 bytes of LDS each) = nonzeros per piece
+constexpr int kBundleSlices = kBundleCap / kWave;
+#ifndef SPMV_WAVE_WINDOW
+#define SPMV_WAVE_WINDOW 8960
+#endif
+constexpr int kWaveWindow = SPMV_WAVE_WINDOW;      // entries of x a workgroup keeps in LDS (35 KiB): a band of 8192 + its 512 rows + slack
+constexpr int kWaveBlock = 512;                    // rows (threads) of a workgroup that shares a window
+#ifndef SPMV_PIECE_LEN
+#define SPMV_PIECE_LEN 1024
+#endif
+constexpr int kPieceLen = SPMV_PIECE_LEN;          // nonzeros of a piece of a long row (one wavefront of k_wave_pieces)
+static_assert(kBundleCap % (4 * kWave) == 0 && kWaveWindow % 32 == 0, "bundle geometry");
+
+// Buffer descriptors (wave-uniform base in scalar registers, 32-bit lane offsets, immediate slice offsets, reads past the
+// end return 0): the streamed loads of a run share ONE offset register and need no predicates, and a gather's address is
+// the column itself.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *p, uint32_t bytes)
 {
-    __shared__ float prod_all[kBlock / kWave][kBundleCap];
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ const void *uniform_ptr(const void *p)
+{
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (const void *)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ int32_t buf_i32(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0);
+}
+
+// the nonzeros [k0, k0 + len) (len <= kBundleCap, wave-uniform): all their loads issued at once, in groups of four slices
+// that are skipped past the end; slot u of a lane = nonzero k0 + u*64 + lane (column 0, value 0 past the end)
+template <int S>
+__device__ __forceinline__ void bundle_loads(int lane, int64_t k0, int32_t len, const int32_t *__restrict__ col_idx,
+                                             const float *__restrict__ vals, int32_t (&c)[S], float (&v)[S])
+{
+    constexpr int kBundleSlices = S;
+    const __amdgpu_buffer_rsrc_t cr = rsrc_of(uniform_ptr(col_idx + k0), (uint32_t)len * 4u);
+    const __amdgpu_buffer_rsrc_t vr = rsrc_of(uniform_ptr(vals + k0), (uint32_t)len * 4u);
+    int lane4 = lane * 4;               // + the slice's immediate offset
+    asm volatile("" : "+v"(lane4));     // (opaque: known bits would turn the add into an OR that is not folded into offset:)
+#pragma unroll
+    for (int t = 0; t < kBundleSlices; t += 4) {
+        if (t * kWave < len) {
+#pragma unroll
+            for (int u = t; u < t + 4; ++u) {
+                c[u] = buf_i32(cr, lane4 + u * (kWave * 4));
+                v[u] = buf_f32(vr, lane4 + u * (kWave * 4));
+            }
+        } else {
+#pragma unroll
+            for (int u = t; u < t + 4; ++u) { c[u] = 0; v[u] = 0.0f; }
+        }
+    }
+}
+// v[u] *= x[c[u]]: from the window in LDS (win: entries [lo, lo + kWaveWindow) of x, every column of the caller's rows
+// inside it -- the plan checked) or from memory, through a descriptor when x is shorter than 4 GiB (BUFX), else plain loads
+template <bool BUFX, int S>
+__device__ __forceinline__ void bundle_multiply(int lane, int32_t len, __amdgpu_buffer_rsrc_t xr, const float *__restrict__ x,
+                                                const float *win, int32_t lo, const int32_t (&c)[S], float (&v)[S])
+{
+    constexpr int kBundleSlices = S;
+#pragma unroll
+    for (int t = 0; t < kBundleSlices; t += 4) {
+        if (t * kWave < len) {
+            float xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#ifdef SPMV_R_NOGATHER
+                const int32_t cc = (lo < 0 ? 0 : lo) + (((t + u) * kWave + lane) & 1023);
+#else
+                const int32_t cc = c[t + u];
+#endif
+                if (win) xv[u] = win[min((uint32_t)(cc - lo), (uint32_t)(kWaveWindow - 1))];   // (slots past the end hold column 0)
+                else xv[u] = BUFX ? buf_f32(xr, cc << 2) : x[cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[t + u] *= xv[u];
+        }
+    }
+}
+
+// the workgroup's window: entries [lo, lo + kWaveWindow) of x into LDS (zeros past the end of x)
+template <int BLOCK>
+__device__ __forceinline__ void load_window(float *win, const float *__restrict__ x, int64_t lo, int64_t cols)
+{
+    for (int i = threadIdx.x * 4; i < kWaveWindow; i += BLOCK * 4) {
+        const int64_t g = lo + i;
+        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (g + 3 < cols) q = *reinterpret_cast<const float4 *>(x + g);
+        else {
+            if (g < cols) q.x = x[g];
+            if (g + 1 < cols) q.y = x[g + 1];
+            if (g + 2 < cols) q.z = x[g + 2];
+        }
+        *reinterpret_cast<float4 *>(win + i) = q;
+    }
+}
+
+// A workgroup = 512 rows = 8 wavefronts.  MODE 0: x gathered from memory.  MODE 1: from the block's window in LDS where the
+// plan has one (blk_lo >= 0).  MODE 2: the plan pass for MODE 1 -- the column span of the block's rows, the long ones
+// excepted -> blk_lo.
+template <bool BUFX, int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t cols, uint32_t x_bytes,
+                                                       const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
+                                                       const float *__restrict__ vals, const float *__restrict__ x,
+                                                       float *__restrict__ y, int32_t *__restrict__ blk_lo)
+{
+    constexpr int kWaves = BLOCK / kWave;
+    __shared__ float prod_all[MODE == 2 ? 1 : kWaves][MODE == 2 ? 1 : kBundleCap];
+    __shared__ __attribute__((aligned(16))) float win_lds[MODE == 1 ? kWaveWindow : 4];
+    __shared__ int32_t smin[kWaves], smax[kWaves];
     const int lane = threadIdx.x & (kWave - 1);
-    float *prod = prod_all[threadIdx.x >> 6];
-    const int64_t r0 = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kWave;
-    if (r0 >= rows) return;  // wave-uniform; no workgroup barrier below
+    const int wave = threadIdx.x >> 6;
+    float *prod = prod_all[MODE == 2 ? 0 : wave];
+    const __amdgpu_buffer_rsrc_t xr = rsrc_of(x, x_bytes);
+    const int64_t r0 = ((int64_t)blockIdx.x * kWaves + wave) * kWave;
     const int64_t r = r0 + lane;
     const bool live = r < rows;
     const int32_t b = row_ptr[live ? r : rows], e = row_ptr[live ? r + 1 : rows];
-    const int n = (int)((rows - r0 < kWave) ? rows - r0 : kWave);
-    // as many consecutive rows as fit the slice at a time (usually all 64); a row that does not fit on its own is
-    // added straight from memory by the whole wave, four slices in flight
-    int i0 = 0;
+    const int n = r0 < rows ? (int)((rows - r0 < kWave) ? rows - r0 : kWave) : 0;
+    const unsigned long long long_mask = __ballot(e - b > kBundleCap);     // k_wave_pieces' rows
+    int32_t lo = -1;
+    if (MODE == 1) lo = __builtin_amdgcn_readfirstlane(blk_lo[blockIdx.x]);
+    const float *win = (MODE == 1 && lo >= 0) ? win_lds : nullptr;
+
+    // the next run: the rows from `from` on that are not long and hold at most kBundleCap nonzeros together
+    int i0 = 0, i1 = 0;
+    int32_t sb = 0, len = 0;
+    auto next_run = [&](int from) {
+        i0 = from;
+        while (i0 < n && ((long_mask >> i0) & 1ULL)) ++i0;
+        i1 = i0;
+        len = 0;
+        if (i0 >= n) return;
+        sb = __builtin_amdgcn_readfirstlane(__shfl(b, i0));
+        const unsigned long long stop = long_mask >> i0;                   // the first long row after i0 ends the run
+        const int room = stop ? __ffsll((long long)stop) - 1 : kWave;
+        i1 = i0 + __popcll(__ballot(lane >= i0 && lane < n && lane < i0 + room && e - sb <= kBundleCap));   // e ascends
+        len = __builtin_amdgcn_readfirstlane(__shfl(e, i1 - 1)) - sb;
+    };
+    int32_t c[kBundleSlices];
+    float v[kBundleSlices];
+    next_run(0);
+    bundle_loads(lane, sb, len, col_idx, vals, c, v);
+    if (MODE == 1) {
+        if (win) load_window<BLOCK>(win_lds, x, lo, cols);
+        __syncthreads();
+    }
+    int32_t cmin = 0x7fffffff, cmax = -1;
     while (i0 < n) {
-        const int32_t sb = __shfl(b, i0);
-        const unsigned long long fit = __ballot(lane >= i0 && lane < n && e - sb <= kBundleCap);   // e ascends
-        const int cnt = __popcll(fit);
-        if (cnt == 0) {
-            const float acc = wave_row<true>(lane, sb, __shfl(e, i0), col_idx, vals, x);
-            if (lane == 0) y[r0 + i0] = acc;
-            ++i0;
+        if (MODE == 2) {
+#pragma unroll
+            for (int u = 0; u < kBundleSlices; ++u) {
+                if (u * kWave + lane < len) { cmin = min(cmin, c[u]); cmax = max(cmax, c[u]); }
+            }
+            next_run(i1);
+            bundle_loads(lane, sb, len, col_idx, vals, c, v);
             continue;
         }
-        const int i1 = i0 + cnt;
-        const int32_t se = __shfl(e, i1 - 1);
-        {
-            // four 64-wide slices per trip: 8 streamed loads, then 4 gathers, are issued before the first use (the
-            // pipelining wsp_kernel_v1 adds to v0, wsp.cu:78-134, at wave64 width)
-            int32_t k = sb + lane;
-            for (; k + 3 * kWave < se; k += 4 * kWave) {
-                const int32_t c0 = col_idx[k], c1 = col_idx[k + kWave], c2 = col_idx[k + 2 * kWave], c3 = col_idx[k + 3 * kWave];
-                const float v0 = vals[k], v1 = vals[k + kWave], v2 = vals[k + 2 * kWave], v3 = vals[k + 3 * kWave];
-                const float x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-                prod[k - sb] = v0 * x0;
-                prod[k - sb + kWave] = v1 * x1;
-                prod[k - sb + 2 * kWave] = v2 * x2;
-                prod[k - sb + 3 * kWave] = v3 * x3;
+        bundle_multiply<BUFX, kBundleSlices>(lane, len, xr, x, win, lo, c, v);
+#pragma unroll
+        for (int t = 0; t < kBundleSlices; t += 4) {
+            if (t * kWave < len) {
+#pragma unroll
+                for (int u = t; u < t + 4; ++u) prod[u * kWave + lane] = v[u];
             }
-            for (; k < se; k += kWave) prod[k - sb] = vals[k] * x[col_idx[k]];
         }
-        const bool mine = lane >= i0 && lane < i1;
+        // this run's rows and range; the next run's loads go out under this run's sums
+        const int a0 = i0, a1 = i1;
+        const int32_t asb = sb;
+        next_run(a1);
+        bundle_loads(lane, sb, len, col_idx, vals, c, v);
+        const bool mine = lane >= a0 && lane < a1;
         const bool is_long = mine && e - b > kWave;
         if (mine && !is_long) {
             float acc = 0.0f;
-            for (int32_t k = b; k < e; ++k) acc += prod[k - sb];
+            int32_t k = b - asb;
+            const int32_t ke = e - asb;
+            for (; k + 3 < ke; k += 4) {       // four reads in flight, added in order
+                const float p0 = prod[k], p1 = prod[k + 1], p2 = prod[k + 2], p3 = prod[k + 3];
+                acc += p0;
+                acc += p1;
+                acc += p2;
+                acc += p3;
+            }
+            for (; k < ke; ++k) acc += prod[k];
             y[r] = acc;
         }
         unsigned long long todo = __ballot(is_long);
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const int32_t lb = __shfl(b, src), le = __shfl(e, src);
-            float acc = 0.0f;
-            for (int32_t k = lb + lane; k < le; k += kWave) acc += prod[k - sb];
-            acc = wave_reduce_sum(acc);
+            const int32_t lb = __shfl(b, src) - asb, le = __shfl(e, src) - asb;
+            float s0 = 0.0f, s1 = 0.0f;
+            int32_t k = lb + lane;
+            for (; k + kWave < le; k += 2 * kWave) {
+                s0 += prod[k];
+                s1 += prod[k + kWave];
+            }
+            if (k < le) s0 += prod[k];
+            const float acc = wave_reduce_sum(s0 + s1);
             if (lane == 0) y[r0 + src] = acc;
         }
-        i0 = i1;
+        // (the next run's products overwrite prod only after every lane of this wave is past its reads: one wave,
+        // program order)
+    }
+    if (MODE == 2) {
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            cmin = min(cmin, __shfl_xor(cmin, o));
+            cmax = max(cmax, __shfl_xor(cmax, o));
+        }
+        if (lane == 0) { smin[wave] = cmin; smax[wave] = cmax; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < kWaves; ++i) { cmin = min(cmin, smin[i]); cmax = max(cmax, smax[i]); }
+            int32_t w = 0;                                  // (no short nonzeros: any window will do)
+            if (cmax >= cmin) {
+                w = cmin & ~31;
+                if (cmax - w >= kWaveWindow) w = -1;
+            }
+            blk_lo[blockIdx.x] = w;
+        }
+    }
+}
+
+// one wavefront per piece of kPieceLen nonzeros, wherever on the chip there is room: partial[p] = sum of its products (x from
+// memory: the long rows' columns are the wide ones; no LDS, eight waves per SIMD, 2 x 16 loads in flight each)
+template <bool BUFX>
+__global__ __launch_bounds__(kBlock) void k_wave_pieces(int npieces, uint32_t x_bytes, const int32_t *__restrict__ piece_k0,
+                                                        const int32_t *__restrict__ piece_len,
+                                                        const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
+                                                        const float *__restrict__ x, float *__restrict__ partial)
+{
+    constexpr int S = kPieceLen / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int p = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (p >= npieces) return;   // wave-uniform
+    const __amdgpu_buffer_rsrc_t xr = rsrc_of(x, x_bytes);
+    const int32_t k0 = __builtin_amdgcn_readfirstlane(piece_k0[p]), len = __builtin_amdgcn_readfirstlane(piece_len[p]);
+    int32_t c[S];
+    float v[S];
+    bundle_loads<S>(lane, k0, len, col_idx, vals, c, v);
+    bundle_multiply<BUFX, S>(lane, len, xr, x, nullptr, 0, c, v);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < S; t += 4) {
+        if (t * kWave < len) {      // (a slot past the end holds 0 * x[0], which is not 0 when x[0] is Inf or NaN)
+            a0 += t * kWave + lane < len ? v[t] : 0.0f;
+            a1 += (t + 1) * kWave + lane < len ? v[t + 1] : 0.0f;
+            a2 += (t + 2) * kWave + lane < len ? v[t + 2] : 0.0f;
+            a3 += (t + 3) * kWave + lane < len ? v[t + 3] : 0.0f;
+        }
+    }
+    const float acc = wave_reduce_sum((a0 + a1) + (a2 + a3));
+    if (lane == 0) partial[p] = acc;
+}
+
+// one thread per long row: its pieces added in order
+__global__ __launch_bounds__(kBlock) void k_wave_combine(int n_long, const int32_t *__restrict__ long_row,
+                                                         const int32_t *__restrict__ long_first,
+                                                         const float *__restrict__ partial, float *__restrict__ y)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_long) return;
+    float acc = 0.0f;
+    for (int p = long_first[i]; p < long_first[i + 1]; ++p) acc += partial[p];
+    y[long_row[i]] = acc;
+}
+
+// ---- the plan of SPMV_WAVE_PIPE: the rows of more than kBundleCap nonzeros and their pieces, in row order
+constexpr int kWavePlanBlock = kWaveBlock;   // (so that the per-block piece counts are the compute kernel's)
+// exclusive prefix of v over the workgroup's threads (total returned in *total by every thread)
+__device__ __forceinline__ int block_exclusive_scan(int v, int *lds /* 16 + 1 */, int *total)
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == kWave - 1) lds[wave] = incl;
+    __syncthreads();
+    int base = 0, sum = 0;
+    for (int w = 0; w < kWavePlanBlock / kWave; ++w) {
+        if (w < wave) base += lds[w];
+        sum += lds[w];
+    }
+    __syncthreads();
+    *total = sum;
+    return base + incl - v;
+}
+__global__ __launch_bounds__(kWavePlanBlock) void k_wave_plan_count(int64_t rows, const int32_t *__restrict__ row_ptr,
+                                                                    int32_t *__restrict__ blk_long, int32_t *__restrict__ blk_pieces)
+{
+    __shared__ int lds[kWavePlanBlock / kWave];
+    const int64_t r = (int64_t)blockIdx.x * kWavePlanBlock + threadIdx.x;
+    const int32_t n = r < rows ? row_ptr[r + 1] - row_ptr[r] : 0;
+    const int pieces = n > kBundleCap ? (n + kPieceLen - 1) / kPieceLen : 0;
+    int tl, tp;
+    (void)block_exclusive_scan(pieces ? 1 : 0, lds, &tl);
+    (void)block_exclusive_scan(pieces, lds, &tp);
+    if (threadIdx.x == 0) { blk_long[blockIdx.x] = tl; blk_pieces[blockIdx.x] = tp; }
+}
+__global__ __launch_bounds__(kWavePlanBlock) void k_wave_plan_fill(int64_t rows, const int32_t *__restrict__ row_ptr,
+                                                                   const int32_t *__restrict__ blk_long,
+                                                                   const int32_t *__restrict__ blk_pieces,
+                                                                   int32_t *__restrict__ long_row, int32_t *__restrict__ long_first,
+                                                                   int32_t *__restrict__ piece_k0, int32_t *__restrict__ piece_len)
+{
+    __shared__ int lds[kWavePlanBlock / kWave];
+    const int64_t r = (int64_t)blockIdx.x * kWavePlanBlock + threadIdx.x;
+    const int32_t b = r < rows ? row_ptr[r] : 0, e = r < rows ? row_ptr[r + 1] : 0;
+    const int pieces = e - b > kBundleCap ? (e - b + kPieceLen - 1) / kPieceLen : 0;
+    int tl, tp;
+    const int li = blk_long[blockIdx.x] + block_exclusive_scan(pieces ? 1 : 0, lds, &tl);     // blk_*: exclusive prefixes
+    const int pi = blk_pieces[blockIdx.x] + block_exclusive_scan(pieces, lds, &tp);
+    if (pieces) {
+        long_row[li] = (int32_t)r;
+        long_first[li] = pi;
+        for (int j = 0; j < pieces; ++j) {
+            const int32_t k0 = b + j * kPieceLen;
+            piece_k0[pi + j] = k0;
+            piece_len[pi + j] = e - k0 < kPieceLen ? e - k0 : kPieceLen;
+        }
     }
 }
 
@@ -306,7 +609,98 @@ int launch_scalar(const spmv_csr &h, const float *x, float *y, hipStream_t s)
     return check_launch("k_scalar");
 }
 
-int launch_wave(const spmv_csr &h, const float *x, float *y, bool pipelined, hipStream_t s)
+void destroy_wave(WavePlan &p)
+{
+    (void)hipFree(p.d_long_row);
+    (void)hipFree(p.d_long_first);
+    (void)hipFree(p.d_piece_k0);
+    (void)hipFree(p.d_piece_len);
+    (void)hipFree(p.d_partial);
+    (void)hipFree(p.d_blk_lo);
+    (void)hipFree(p.d_blk_piece);
+    p = WavePlan{};
+}
+
+template <int MODE>
+static void launch_bundle(const spmv_csr &h, const WavePlan &p, const float *x, float *y, int32_t *blk_lo, hipStream_t s)
+{
+    const dim3 grid((unsigned)p.blocks);
+    if (h.cols < (1LL << 30))
+        hipLaunchKernelGGL((k_wave_bundle<true, kWaveBlock, MODE>), grid, dim3(kWaveBlock), 0, s, h.rows, h.cols,
+                           (uint32_t)(h.cols * 4), h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, blk_lo);
+    else
+        hipLaunchKernelGGL((k_wave_bundle<false, kWaveBlock, MODE>), grid, dim3(kWaveBlock), 0, s, h.rows, h.cols, 0u,
+                           h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, blk_lo);
+}
+
+// The plan of SPMV_WAVE_PIPE, a function of row_ptr and col_idx (not of the values): the rows of more than kBundleCap
+// nonzeros with their pieces, in row order (so that the pieces of a block of 512 rows are consecutive), and the window
+// of x of every block where its columns fit one.  Waits for the stream.
+int plan_wave(spmv_csr &h, hipStream_t s)
+{
+    if (h.plan_wave.ready) return SPMV_OK;
+    destroy_wave(h.plan_wave);
+    WavePlan &p = h.plan_wave;
+    if (h.rows == 0 || h.nnz > 32 * h.rows) { p.ready = true; return SPMV_OK; }   // (long-row matrices run k_wave<true>)
+    const int64_t nblk = (h.rows + kWaveBlock - 1) / kWaveBlock;
+    if (!grid_ok(nblk)) return SPMV_ERR_INVALID;
+    p.blocks = nblk;
+    DevPtr<int32_t> d_bl, d_bp, blk_lo;
+    SPMV_HIP_TRY(d_bl.alloc((size_t)nblk));
+    SPMV_HIP_TRY(d_bp.alloc((size_t)nblk + 1));
+    SPMV_HIP_TRY(blk_lo.alloc((size_t)nblk));
+    hipLaunchKernelGGL(k_wave_plan_count, dim3((unsigned)nblk), dim3(kWavePlanBlock), 0, s, h.rows, h.d_row_ptr, d_bl.p, d_bp.p);
+    if (int rc = check_launch("k_wave_plan_count")) return rc;
+    std::vector<int32_t> bl((size_t)nblk), bp((size_t)nblk + 1);
+    SPMV_HIP_TRY(hipMemcpyAsync(bl.data(), d_bl.p, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipMemcpyAsync(bp.data(), d_bp.p, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    int64_t nl = 0, np = 0;
+    for (int64_t i = 0; i < nblk; ++i) {
+        const int32_t l = bl[(size_t)i], q = bp[(size_t)i];
+        bl[(size_t)i] = (int32_t)nl;
+        bp[(size_t)i] = (int32_t)np;
+        nl += l;
+        np += q;
+    }
+    if (np > 0x7fffffffLL) { set_error("SPMV_WAVE_PIPE: %lld pieces", (long long)np); return SPMV_ERR_INVALID; }
+    bp[(size_t)nblk] = (int32_t)np;
+    p.n_long = (int)nl;
+    p.pieces = (int)np;
+    DevPtr<int32_t> lr, lf, k0, ln;
+    DevPtr<float> part;
+    SPMV_HIP_TRY(lr.alloc((size_t)nl));
+    SPMV_HIP_TRY(lf.alloc((size_t)nl + 1));
+    SPMV_HIP_TRY(k0.alloc((size_t)np));
+    SPMV_HIP_TRY(ln.alloc((size_t)np));
+    SPMV_HIP_TRY(part.alloc((size_t)np));
+    SPMV_HIP_TRY(hipMemcpyAsync(d_bl.p, bl.data(), sizeof(int32_t) * (size_t)nblk, hipMemcpyHostToDevice, s));
+    SPMV_HIP_TRY(hipMemcpyAsync(d_bp.p, bp.data(), sizeof(int32_t) * ((size_t)nblk + 1), hipMemcpyHostToDevice, s));
+    SPMV_HIP_TRY(hipMemcpyAsync(lf.p + nl, &bp[(size_t)nblk], sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (nl) {
+        hipLaunchKernelGGL(k_wave_plan_fill, dim3((unsigned)nblk), dim3(kWavePlanBlock), 0, s, h.rows, h.d_row_ptr, d_bl.p, d_bp.p,
+                           lr.p, lf.p, k0.p, ln.p);
+        if (int rc = check_launch("k_wave_plan_fill")) return rc;
+    }
+    p.d_long_row = lr.release();
+    p.d_long_first = lf.release();
+    p.d_piece_k0 = k0.release();
+    p.d_piece_len = ln.release();
+    p.d_partial = part.release();
+    p.d_blk_piece = d_bp.release();
+    // the windows: the bundle kernel in its plan mode (the same runs and pieces, minimum and maximum column instead of products)
+    launch_bundle<2>(h, p, nullptr, nullptr, blk_lo.p, s);
+    if (int rc = check_launch("k_wave_bundle<plan>")) return rc;
+    std::vector<int32_t> wl((size_t)nblk);
+    SPMV_HIP_TRY(hipMemcpyAsync(wl.data(), blk_lo.p, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));      // (also: bl / bp are host memory of this call)
+    for (int64_t i = 0; i < nblk; ++i) p.win_blocks += wl[(size_t)i] >= 0;
+    p.d_blk_lo = blk_lo.release();
+    p.ready = true;
+    return SPMV_OK;
+}
+
+int launch_wave(spmv_csr &h, const float *x, float *y, bool pipelined, hipStream_t s)
 {
     if (h.rows == 0) return SPMV_OK;
     constexpr int kRowsPerBlock = kBlock / kWave;
@@ -319,10 +713,27 @@ int launch_wave(const spmv_csr &h, const float *x, float *y, bool pipelined, hip
         hipLaunchKernelGGL(k_wave<true>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr, h.d_col_idx,
                            h.d_vals, x, y);
     } else if (bundle) {
-        const int64_t bundles = (h.rows + kWave - 1) / kWave;
-        const int64_t bblocks = (bundles + (kBlock / kWave) - 1) / (kBlock / kWave);
-        hipLaunchKernelGGL(k_wave_bundle, dim3((unsigned)(bblocks ? bblocks : 1)), dim3(kBlock), 0, s, h.rows,
-                           h.d_row_ptr, h.d_col_idx, h.d_vals, x, y);
+        if (int rc = plan_wave(h, s)) return rc;        // (the first run of a handle that was not planned: allocates, waits)
+        const WavePlan &p = h.plan_wave;
+        // windows where at least half of the blocks have one (their 35 KiB leave two workgroups per CU); else every
+        // gather goes to memory, from three workgroups per CU
+        if (2 * p.win_blocks >= p.blocks) launch_bundle<1>(h, p, x, y, p.d_blk_lo, s);
+        else launch_bundle<0>(h, p, x, y, nullptr, s);
+#ifndef SPMV_R_NOLONG
+        if (p.n_long) {
+            if (int rc = check_launch("k_wave_bundle")) return rc;
+            const dim3 pgrid((unsigned)((p.pieces + kRowsPerBlock - 1) / kRowsPerBlock));
+            if (h.cols < (1LL << 30))
+                hipLaunchKernelGGL(k_wave_pieces<true>, pgrid, dim3(kBlock), 0, s, p.pieces, (uint32_t)(h.cols * 4), p.d_piece_k0,
+                                   p.d_piece_len, h.d_col_idx, h.d_vals, x, p.d_partial);
+            else
+                hipLaunchKernelGGL(k_wave_pieces<false>, pgrid, dim3(kBlock), 0, s, p.pieces, 0u, p.d_piece_k0, p.d_piece_len,
+                                   h.d_col_idx, h.d_vals, x, p.d_partial);
+            if (int rc = check_launch("k_wave_pieces")) return rc;
+            hipLaunchKernelGGL(k_wave_combine, dim3((unsigned)((p.n_long + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, p.n_long,
+                               p.d_long_row, p.d_long_first, p.d_partial, y);
+        }
+#endif
     } else {
         hipLaunchKernelGGL(k_wave<false>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr, h.d_col_idx,
                            h.d_vals, x, y);

@@ -139,6 +139,20 @@ struct XskipPlan {
     ValuesStamp stamp;                // which state of vals d_evals is a copy of
 };
 
+// SPMV_WAVE_PIPE (kernels_rows.hip): the rows too long for a wavefront's bundle, cut into pieces for the whole chip
+struct WavePlan {
+    bool ready = false;
+    int n_long = 0, pieces = 0;
+    int32_t *d_long_row = nullptr;    // [n_long] the rows, ascending
+    int32_t *d_long_first = nullptr;  // [n_long + 1] first piece of every row
+    int32_t *d_piece_k0 = nullptr;    // [pieces] first nonzero of a piece
+    int32_t *d_piece_len = nullptr;   // [pieces] its length (<= 1024)
+    float *d_partial = nullptr;       // [pieces] scratch of a run: the pieces' sums
+    int32_t *d_blk_lo = nullptr;      // [blocks] first entry of the x window of every 512 rows, -1: none
+    int32_t *d_blk_piece = nullptr;   // [blocks + 1] first piece of every block (the pieces are in row order)
+    int64_t blocks = 0, win_blocks = 0;   // blocks of 512 rows, and how many have a window
+};
+
 }  // namespace spmv
 
 struct spmv_tcsr;    // kernels_tcsr.hip
@@ -161,6 +175,7 @@ struct spmv_csr {
     spmv::PanelPlan plan_auto_panel;   // SPMV_AUTO where it resolved to the panel family (its own: see refresh_panel)
     bool auto_made_tiled = false;  // SPMV_AUTO made the TILED plan it looked at (and may release it)
     spmv::XskipPlan plan_xskip;    // SPMV_XSKIP
+    spmv::WavePlan plan_wave;      // SPMV_WAVE_PIPE
     int auto_variant = -1;         // SPMV_AUTO: the variant its plan chose (-1 = not planned)
     uint64_t values_gen = 0;       // bumped by spmv_csr_values_changed: plans that copied vals before that are stale
 };
@@ -169,7 +184,9 @@ namespace spmv {
 
 // ---- kernel launchers (each enqueues on `s`, returns a status) -------------
 int launch_scalar(const spmv_csr &h, const float *x, float *y, hipStream_t s);
-int launch_wave(const spmv_csr &h, const float *x, float *y, bool pipelined, hipStream_t s);
+int launch_wave(spmv_csr &h, const float *x, float *y, bool pipelined, hipStream_t s);
+int plan_wave(spmv_csr &h, hipStream_t s);
+void destroy_wave(WavePlan &p);
 int launch_vector(const spmv_csr &h, const float *x, float *y, hipStream_t s);
 int launch_adaptive(const spmv_csr &h, const float *x, float *y, bool tiled, hipStream_t s);
 int launch_panel(const spmv_csr &h, const float *x, float *y, hipStream_t s);
