@@ -370,8 +370,8 @@ int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream)
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
         case SPMV_AUTO: return plan_auto(*h, s);
-        case SPMV_SCALAR:
         case SPMV_WAVE: return SPMV_OK;
+        case SPMV_SCALAR:        // (the x windows of the bundle kernel, which SPMV_SCALAR runs with ordered sums)
         case SPMV_WAVE_PIPE: return plan_wave(*h, s);
         case SPMV_VECTOR: return plan_vector(*h, s);
         case SPMV_ADAPTIVE: return plan_adaptive(*h, false, s);
@@ -544,10 +544,10 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
     }
     const ChunkPlan *p = variant == SPMV_ADAPTIVE ? &h->plan_adaptive : (variant == SPMV_TILED ? &h->plan_tiled : nullptr);
     if (variant == SPMV_VECTOR) snprintf(buf, (size_t)n, "lanes_per_row=%d", h->vector_width);
-    else if (variant == SPMV_WAVE_PIPE) {
+    else if (variant == SPMV_WAVE_PIPE || variant == SPMV_SCALAR) {
         if (!h->plan_wave.ready) snprintf(buf, (size_t)n, "not planned (the first run plans)");
-        else snprintf(buf, (size_t)n, "long_rows=%d pieces=%d blocks=%lld blocks_with_x_window=%lld", h->plan_wave.n_long,
-                      h->plan_wave.pieces, (long long)h->plan_wave.blocks, (long long)h->plan_wave.win_blocks);
+        else snprintf(buf, (size_t)n, "long_rows=%d pieces=%d block_rows=%d blocks=%lld blocks_with_x_window=%lld", h->plan_wave.n_long,
+                      h->plan_wave.pieces, h->plan_wave.block_rows, (long long)h->plan_wave.blocks, (long long)h->plan_wave.win_blocks);
     }
     else if (variant == SPMV_PANEL && panel->ready && panel->sorted_mode)
         snprintf(buf, (size_t)n, "sorted_blocks=%d rows_per_block=%d wavefronts=%d lines_per_nonzero=%.3f tail_nonzeros=%lld wide_blocks=%lld model_cost=%.3f",

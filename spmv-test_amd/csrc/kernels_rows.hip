@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__
 }
 
 // SPMV_WAVE_PIPE (the slot of wsp_kernel_v1, the reference's unrolled / prefetching version, wsp.cu:59-138): a wavefront
-// owns 64 consecutive rows, eight wavefronts (512 rows) make a workgroup.
+// owns 64 consecutive rows; 8 or 16 wavefronts (512 or 1024 rows) make a workgroup.
 //   * Rows of up to kBundleCap nonzeros: the wave takes them in runs of consecutive rows that hold at most kBundleCap
 //     nonzeros together, streams that contiguous range with coalesced loads -- lane-consecutive nonzeros, the whole wave busy
 //     whatever the row lengths, ALL of the run's loads issued before the first use and the next run's loads issued before
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__
 //   * Longer rows are cut by the plan into pieces of kPieceLen nonzeros for k_wave_pieces: one wavefront per piece wherever
 //     on the chip there is room (one coalesced stream + a wave sum into a word of the plan's scratch); k_wave_combine then
 //     adds a row's pieces in order.
-//   * x comes from a window in LDS -- the entries [lo, lo + kWaveWindow) that hold every column of the block's 512 rows
+//   * x comes from a window in LDS -- the entries [lo, lo + wave_window) that hold every column of the block's rows
 //     (the long ones excepted: theirs are gathered from memory), found by the plan -- where such a window exists, else
 //     from memory.
 // The plan is a function of row_ptr and col_idx (not of the values), made by spmv_csr_plan or by the first run.
@@ -220,16 +220,17 @@ __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__
 #endif
 constexpr int kBundleCap = SPMV_BUNDLE_CAP;        // products per wave and run (4 bytes of LDS each) = nonzeros per piece
 constexpr int kBundleSlices = kBundleCap / kWave;
-#ifndef SPMV_WAVE_WINDOW
-#define SPMV_WAVE_WINDOW 8960
-#endif
-constexpr int kWaveWindow = SPMV_WAVE_WINDOW;      // entries of x a workgroup keeps in LDS (35 KiB): a band of 8192 + its 512 rows + slack
-constexpr int kWaveBlock = 512;                    // rows (threads) of a workgroup that shares a window
+// rows (= threads) of a workgroup that shares a window, and the entries of x it keeps in LDS: a band of 8192 + its rows +
+// slack.  512 rows / 35 KiB (three workgroups per CU) for matrices of less than 2 Mi rows, where the grid is a few
+// rounds of workgroups and whole rounds count (config 2: 0.0377 ms against 0.0413); 1024 rows / 37 KiB (two workgroups =
+// 32 wavefronts per CU, half the window traffic) above (config 4: 0.632 against 0.716 ms, config 3: 0.372 against 0.391).
+__host__ __device__ constexpr int wave_window(int block) { return block == 1024 ? 9472 : 8960; }
+constexpr int64_t kWaveBigRows = 2 << 20;
 #ifndef SPMV_PIECE_LEN
 #define SPMV_PIECE_LEN 1024
 #endif
 constexpr int kPieceLen = SPMV_PIECE_LEN;          // nonzeros of a piece of a long row (one wavefront of k_wave_pieces)
-static_assert(kBundleCap % (4 * kWave) == 0 && kWaveWindow % 32 == 0, "bundle geometry");
+static_assert(kBundleCap % (4 * kWave) == 0 && wave_window(512) % 32 == 0 && wave_window(1024) % 32 == 0, "bundle geometry");
 
 // Buffer descriptors (wave-uniform base in scalar registers, 32-bit lane offsets, immediate slice offsets, reads past the
 // end return 0): the streamed loads of a run share ONE offset register and need no predicates, and a gather's address is
@@ -278,11 +279,11 @@ __device__ __forceinline__ void bundle_loads(int lane, int64_t k0, int32_t len, 
         }
     }
 }
-// v[u] *= x[c[u]]: from the window in LDS (win: entries [lo, lo + kWaveWindow) of x, every column of the caller's rows
+// v[u] *= x[c[u]]: from the window in LDS (win: entries [lo, lo + wlast] of x, every column of the caller's rows
 // inside it -- the plan checked) or from memory, through a descriptor when x is shorter than 4 GiB (BUFX), else plain loads
 template <bool BUFX, int S>
 __device__ __forceinline__ void bundle_multiply(int lane, int32_t len, __amdgpu_buffer_rsrc_t xr, const float *__restrict__ x,
-                                                const float *win, int32_t lo, const int32_t (&c)[S], float (&v)[S])
+                                                const float *win, int32_t lo, uint32_t wlast, const int32_t (&c)[S], float (&v)[S])
 {
     constexpr int kBundleSlices = S;
 #pragma unroll
@@ -296,7 +297,7 @@ __device__ __forceinline__ void bundle_multiply(int lane, int32_t len, __amdgpu_
 #else
                 const int32_t cc = c[t + u];
 #endif
-                if (win) xv[u] = win[min((uint32_t)(cc - lo), (uint32_t)(kWaveWindow - 1))];   // (slots past the end hold column 0)
+                if (win) xv[u] = win[min((uint32_t)(cc - lo), wlast)];   // (slots past the end hold column 0)
                 else xv[u] = BUFX ? buf_f32(xr, cc << 2) : x[cc];
             }
 #pragma unroll
@@ -305,11 +306,11 @@ __device__ __forceinline__ void bundle_multiply(int lane, int32_t len, __amdgpu_
     }
 }
 
-// the workgroup's window: entries [lo, lo + kWaveWindow) of x into LDS (zeros past the end of x)
+// the workgroup's window: entries [lo, lo + wave_window(BLOCK)) of x into LDS (zeros past the end of x)
 template <int BLOCK>
 __device__ __forceinline__ void load_window(float *win, const float *__restrict__ x, int64_t lo, int64_t cols)
 {
-    for (int i = threadIdx.x * 4; i < kWaveWindow; i += BLOCK * 4) {
+    for (int i = threadIdx.x * 4; i < wave_window(BLOCK); i += BLOCK * 4) {
         const int64_t g = lo + i;
         float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (g + 3 < cols) q = *reinterpret_cast<const float4 *>(x + g);
@@ -322,10 +323,13 @@ __device__ __forceinline__ void load_window(float *win, const float *__restrict_
     }
 }
 
-// A workgroup = 512 rows = 8 wavefronts.  MODE 0: x gathered from memory.  MODE 1: from the block's window in LDS where the
+// A workgroup = BLOCK rows = BLOCK / 64 wavefronts.  MODE 0: x gathered from memory.  MODE 1: from the block's window in LDS where the
 // plan has one (blk_lo >= 0).  MODE 2: the plan pass for MODE 1 -- the column span of the block's rows, the long ones
 // excepted -> blk_lo.
-template <bool BUFX, int BLOCK, int MODE>
+// ORDERED (SPMV_SCALAR's use of this kernel): every row is added in ascending k with one rounding per product and per add,
+// the host loop's arithmetic -- a row longer than a wavefront through a readlane chain over its products in LDS, a row
+// longer than a run straight from memory by its wave (scalar_row_by_wave) instead of in pieces.
+template <bool BUFX, int BLOCK, int MODE, bool ORDERED>
 __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t cols, uint32_t x_bytes,
                                                        const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
                                                        const float *__restrict__ vals, const float *__restrict__ x,
@@ -333,7 +337,8 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
 {
     constexpr int kWaves = BLOCK / kWave;
     __shared__ float prod_all[MODE == 2 ? 1 : kWaves][MODE == 2 ? 1 : kBundleCap];
-    __shared__ __attribute__((aligned(16))) float win_lds[MODE == 1 ? kWaveWindow : 4];
+    constexpr int kWindow = wave_window(BLOCK);
+    __shared__ __attribute__((aligned(16))) float win_lds[MODE == 1 ? kWindow : 4];
     __shared__ int32_t smin[kWaves], smax[kWaves];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
             bundle_loads(lane, sb, len, col_idx, vals, c, v);
             continue;
         }
-        bundle_multiply<BUFX, kBundleSlices>(lane, len, xr, x, win, lo, c, v);
+        bundle_multiply<BUFX, kBundleSlices>(lane, len, xr, x, win, lo, (uint32_t)(kWindow - 1), c, v);
 #pragma unroll
         for (int t = 0; t < kBundleSlices; t += 4) {
             if (t * kWave < len) {
@@ -417,18 +422,43 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const int32_t lb = __shfl(b, src) - asb, le = __shfl(e, src) - asb;
-            float s0 = 0.0f, s1 = 0.0f;
-            int32_t k = lb + lane;
-            for (; k + kWave < le; k += 2 * kWave) {
-                s0 += prod[k];
-                s1 += prod[k + kWave];
+            float acc;
+            if (ORDERED) {
+                acc = 0.0f;     // wave-uniform
+                for (int32_t k0 = lb; k0 < le; k0 += kWave) {
+                    const float pr = k0 + lane < le ? prod[k0 + lane] : 0.0f;
+                    const int m = le - k0 < kWave ? le - k0 : kWave;
+                    if (m == kWave) {
+#pragma unroll
+                        for (int l = 0; l < kWave; ++l)
+                            acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), l));
+                    } else {
+                        for (int l = 0; l < m; ++l) acc = acc + __shfl(pr, l);
+                    }
+                }
+            } else {
+                float s0 = 0.0f, s1 = 0.0f;
+                int32_t k = lb + lane;
+                for (; k + kWave < le; k += 2 * kWave) {
+                    s0 += prod[k];
+                    s1 += prod[k + kWave];
+                }
+                if (k < le) s0 += prod[k];
+                acc = wave_reduce_sum(s0 + s1);
             }
-            if (k < le) s0 += prod[k];
-            const float acc = wave_reduce_sum(s0 + s1);
             if (lane == 0) y[r0 + src] = acc;
         }
         // (the next run's products overwrite prod only after every lane of this wave is past its reads: one wave,
         // program order)
+    }
+    if (ORDERED && MODE != 2) {
+        unsigned long long todo = long_mask;
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const float acc = scalar_row_by_wave(lane, __shfl(b, src), __shfl(e, src), col_idx, vals, x);
+            if (lane == 0) y[r0 + src] = acc;
+        }
     }
     if (MODE == 2) {
 #pragma unroll
@@ -444,7 +474,7 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
             int32_t w = 0;                                  // (no short nonzeros: any window will do)
             if (cmax >= cmin) {
                 w = cmin & ~31;
-                if (cmax - w >= kWaveWindow) w = -1;
+                if (cmax - w >= kWindow) w = -1;
             }
             blk_lo[blockIdx.x] = w;
         }
@@ -468,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_pieces(int npieces, uint32_t x_
     int32_t c[S];
     float v[S];
     bundle_loads<S>(lane, k0, len, col_idx, vals, c, v);
-    bundle_multiply<BUFX, S>(lane, len, xr, x, nullptr, 0, c, v);
+    bundle_multiply<BUFX, S>(lane, len, xr, x, nullptr, 0, 0u, c, v);
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
     for (int t = 0; t < S; t += 4) {
@@ -496,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_combine(int n_long, const int32
 }
 
 // ---- the plan of SPMV_WAVE_PIPE: the rows of more than kBundleCap nonzeros and their pieces, in row order
-constexpr int kWavePlanBlock = kWaveBlock;   // (so that the per-block piece counts are the compute kernel's)
+constexpr int kWavePlanBlock = 512;
 // exclusive prefix of v over the workgroup's threads (total returned in *total by every thread)
 __device__ __forceinline__ int block_exclusive_scan(int v, int *lds /* 16 + 1 */, int *total)
 {
@@ -592,23 +622,6 @@ static bool grid_ok(int64_t blocks)
     return true;
 }
 
-int launch_scalar(const spmv_csr &h, const float *x, float *y, hipStream_t s)
-{
-    if (h.rows == 0) return SPMV_OK;
-    int64_t blocks = (h.rows + kBlock - 1) / kBlock;
-    if (!grid_ok(blocks)) return SPMV_ERR_INVALID;
-    if (h.nnz > 64 * h.rows) {   // long rows: a wavefront per row, still in the oracle's order
-        const int64_t wblocks = (h.rows + (kBlock / kWave) - 1) / (kBlock / kWave);
-        if (!grid_ok(wblocks)) return SPMV_ERR_INVALID;
-        hipLaunchKernelGGL(k_scalar_long, dim3((unsigned)wblocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
-                           h.d_col_idx, h.d_vals, x, y);
-        return check_launch("k_scalar_long");
-    }
-    hipLaunchKernelGGL(k_scalar, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
-                       h.d_col_idx, h.d_vals, x, y);
-    return check_launch("k_scalar");
-}
-
 void destroy_wave(WavePlan &p)
 {
     (void)hipFree(p.d_long_row);
@@ -617,20 +630,25 @@ void destroy_wave(WavePlan &p)
     (void)hipFree(p.d_piece_len);
     (void)hipFree(p.d_partial);
     (void)hipFree(p.d_blk_lo);
-    (void)hipFree(p.d_blk_piece);
     p = WavePlan{};
 }
 
-template <int MODE>
-static void launch_bundle(const spmv_csr &h, const WavePlan &p, const float *x, float *y, int32_t *blk_lo, hipStream_t s)
+template <int MODE, bool ORDERED, int BLOCK>
+static void launch_bundle_block(const spmv_csr &h, const WavePlan &p, const float *x, float *y, int32_t *blk_lo, hipStream_t s)
 {
     const dim3 grid((unsigned)p.blocks);
     if (h.cols < (1LL << 30))
-        hipLaunchKernelGGL((k_wave_bundle<true, kWaveBlock, MODE>), grid, dim3(kWaveBlock), 0, s, h.rows, h.cols,
+        hipLaunchKernelGGL((k_wave_bundle<true, BLOCK, MODE, ORDERED>), grid, dim3(BLOCK), 0, s, h.rows, h.cols,
                            (uint32_t)(h.cols * 4), h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, blk_lo);
     else
-        hipLaunchKernelGGL((k_wave_bundle<false, kWaveBlock, MODE>), grid, dim3(kWaveBlock), 0, s, h.rows, h.cols, 0u,
+        hipLaunchKernelGGL((k_wave_bundle<false, BLOCK, MODE, ORDERED>), grid, dim3(BLOCK), 0, s, h.rows, h.cols, 0u,
                            h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, blk_lo);
+}
+template <int MODE, bool ORDERED = false>
+static void launch_bundle(const spmv_csr &h, const WavePlan &p, const float *x, float *y, int32_t *blk_lo, hipStream_t s)
+{
+    if (p.block_rows == 1024) launch_bundle_block<MODE, ORDERED, 1024>(h, p, x, y, blk_lo, s);
+    else launch_bundle_block<MODE, ORDERED, 512>(h, p, x, y, blk_lo, s);
 }
 
 // The plan of SPMV_WAVE_PIPE, a function of row_ptr and col_idx (not of the values): the rows of more than kBundleCap
@@ -642,13 +660,15 @@ int plan_wave(spmv_csr &h, hipStream_t s)
     destroy_wave(h.plan_wave);
     WavePlan &p = h.plan_wave;
     if (h.rows == 0 || h.nnz > 32 * h.rows) { p.ready = true; return SPMV_OK; }   // (long-row matrices run k_wave<true>)
-    const int64_t nblk = (h.rows + kWaveBlock - 1) / kWaveBlock;
+    const int64_t nblk = (h.rows + kWavePlanBlock - 1) / kWavePlanBlock;     // (of the two list kernels)
     if (!grid_ok(nblk)) return SPMV_ERR_INVALID;
-    p.blocks = nblk;
+    const char *fb = getenv("SPMV_WAVE_BLOCK");
+    p.block_rows = fb && atoi(fb) == 1024 ? 1024 : (fb && atoi(fb) == 512 ? 512 : (h.rows >= kWaveBigRows ? 1024 : 512));
+    p.blocks = (h.rows + p.block_rows - 1) / p.block_rows;
     DevPtr<int32_t> d_bl, d_bp, blk_lo;
     SPMV_HIP_TRY(d_bl.alloc((size_t)nblk));
     SPMV_HIP_TRY(d_bp.alloc((size_t)nblk + 1));
-    SPMV_HIP_TRY(blk_lo.alloc((size_t)nblk));
+    SPMV_HIP_TRY(blk_lo.alloc((size_t)p.blocks));
     hipLaunchKernelGGL(k_wave_plan_count, dim3((unsigned)nblk), dim3(kWavePlanBlock), 0, s, h.rows, h.d_row_ptr, d_bl.p, d_bp.p);
     if (int rc = check_launch("k_wave_plan_count")) return rc;
     std::vector<int32_t> bl((size_t)nblk), bp((size_t)nblk + 1);
@@ -687,17 +707,42 @@ int plan_wave(spmv_csr &h, hipStream_t s)
     p.d_piece_k0 = k0.release();
     p.d_piece_len = ln.release();
     p.d_partial = part.release();
-    p.d_blk_piece = d_bp.release();
     // the windows: the bundle kernel in its plan mode (the same runs and pieces, minimum and maximum column instead of products)
     launch_bundle<2>(h, p, nullptr, nullptr, blk_lo.p, s);
     if (int rc = check_launch("k_wave_bundle<plan>")) return rc;
-    std::vector<int32_t> wl((size_t)nblk);
-    SPMV_HIP_TRY(hipMemcpyAsync(wl.data(), blk_lo.p, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> wl((size_t)p.blocks);
+    SPMV_HIP_TRY(hipMemcpyAsync(wl.data(), blk_lo.p, sizeof(int32_t) * (size_t)p.blocks, hipMemcpyDeviceToHost, s));
     SPMV_HIP_TRY(hipStreamSynchronize(s));      // (also: bl / bp are host memory of this call)
-    for (int64_t i = 0; i < nblk; ++i) p.win_blocks += wl[(size_t)i] >= 0;
+    for (int64_t i = 0; i < p.blocks; ++i) p.win_blocks += wl[(size_t)i] >= 0;
     p.d_blk_lo = blk_lo.release();
     p.ready = true;
     return SPMV_OK;
+}
+
+int launch_scalar(spmv_csr &h, const float *x, float *y, hipStream_t s)
+{
+    if (h.rows == 0) return SPMV_OK;
+    int64_t blocks = (h.rows + kBlock - 1) / kBlock;
+    if (!grid_ok(blocks)) return SPMV_ERR_INVALID;
+    if (h.nnz > 64 * h.rows) {   // long rows: a wavefront per row, still in the oracle's order
+        const int64_t wblocks = (h.rows + (kBlock / kWave) - 1) / (kBlock / kWave);
+        if (!grid_ok(wblocks)) return SPMV_ERR_INVALID;
+        hipLaunchKernelGGL(k_scalar_long, dim3((unsigned)wblocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
+                           h.d_col_idx, h.d_vals, x, y);
+        return check_launch("k_scalar_long");
+    }
+    if (h.nnz <= 32 * h.rows) {
+        // the bundle kernel of SPMV_WAVE_PIPE with its sums in the host loop's order: operands at the depth and from the x
+        // windows that variant's plan provides (made here on the first run of a handle that was not planned)
+        if (int rc = plan_wave(h, s)) return rc;
+        const WavePlan &p = h.plan_wave;
+        if (2 * p.win_blocks >= p.blocks) launch_bundle<1, true>(h, p, x, y, p.d_blk_lo, s);
+        else launch_bundle<0, true>(h, p, x, y, nullptr, s);
+        return check_launch("k_wave_bundle<ordered>");
+    }
+    hipLaunchKernelGGL(k_scalar, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
+                       h.d_col_idx, h.d_vals, x, y);
+    return check_launch("k_scalar");
 }
 
 int launch_wave(spmv_csr &h, const float *x, float *y, bool pipelined, hipStream_t s)

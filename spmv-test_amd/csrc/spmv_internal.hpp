@@ -148,9 +148,9 @@ struct WavePlan {
     int32_t *d_piece_k0 = nullptr;    // [pieces] first nonzero of a piece
     int32_t *d_piece_len = nullptr;   // [pieces] its length (<= 1024)
     float *d_partial = nullptr;       // [pieces] scratch of a run: the pieces' sums
-    int32_t *d_blk_lo = nullptr;      // [blocks] first entry of the x window of every 512 rows, -1: none
-    int32_t *d_blk_piece = nullptr;   // [blocks + 1] first piece of every block (the pieces are in row order)
-    int64_t blocks = 0, win_blocks = 0;   // blocks of 512 rows, and how many have a window
+    int block_rows = 512;             // rows of a bundle workgroup (512 | 1024)
+    int32_t *d_blk_lo = nullptr;      // [blocks] first entry of the x window of every block of block_rows rows, -1: none
+    int64_t blocks = 0, win_blocks = 0;   // blocks of block_rows rows, and how many have a window
 };
 
 }  // namespace spmv
@@ -183,7 +183,7 @@ struct spmv_csr {
 namespace spmv {
 
 // ---- kernel launchers (each enqueues on `s`, returns a status) -------------
-int launch_scalar(const spmv_csr &h, const float *x, float *y, hipStream_t s);
+int launch_scalar(spmv_csr &h, const float *x, float *y, hipStream_t s);
 int launch_wave(spmv_csr &h, const float *x, float *y, bool pipelined, hipStream_t s);
 int plan_wave(spmv_csr &h, hipStream_t s);
 void destroy_wave(WavePlan &p);

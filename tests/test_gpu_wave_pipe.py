@@ -18,10 +18,16 @@ def _describe(prob, capi):
 
 @pytest.mark.parametrize("name,band,scale", [("c3", 8192, 1 / 16), ("c3", 0, 1 / 16), ("c3", 65536, 1 / 16), ("c4", 8192, 1 / 64),
                                              ("c2", 8192, 1 / 4), ("c2", 0, 1 / 4)])
-def test_wave_pipe_on_the_synthetic_laws(pkg, oracle, gpu, name, band, scale):
+@pytest.mark.parametrize("block", [0, 512, 1024])
+def test_wave_pipe_on_the_synthetic_laws(pkg, oracle, gpu, monkeypatch, name, band, scale, block):
     """Scaled-down configs: power-law rows (long rows, pieces), mixed and constant rows; banded columns (every block has a
-    window), uniform and wide bands (none has: the kernel without windows)."""
+    window), uniform and wide bands (none has: the kernel without windows).  Both workgroup sizes (the library takes 1024
+    rows from 2 Mi rows on; SPMV_WAVE_BLOCK forces one at plan time)."""
     capi = pkg.capi
+    if block:
+        monkeypatch.setenv("SPMV_WAVE_BLOCK", str(block))
+    else:
+        monkeypatch.delenv("SPMV_WAVE_BLOCK", raising=False)
     w = pkg.workloads.config(name, band=band, scale=scale)
     prob = synth_problem(pkg, oracle, gpu, w)
     y = prob.run(capi.WAVE_PIPE)
@@ -32,7 +38,8 @@ def test_wave_pipe_on_the_synthetic_laws(pkg, oracle, gpu, name, band, scale):
     lengths = np.diff(prob.row_ptr)
     assert int(d["long_rows"]) == int((lengths > 512).sum())
     assert int(d["pieces"]) == int(((lengths[lengths > 512] + 1023) // 1024).sum())
-    assert int(d["blocks"]) == (prob.rows + 511) // 512
+    assert int(d["block_rows"]) == (block or (1024 if prob.rows >= (2 << 20) else 512))
+    assert int(d["blocks"]) == (prob.rows + int(d["block_rows"]) - 1) // int(d["block_rows"])
     if band == 8192:
         assert int(d["blocks_with_x_window"]) == int(d["blocks"]), d
     if band == 0:
@@ -59,7 +66,7 @@ row_run = st.one_of(
 
 
 @settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(runs=st.lists(row_run, min_size=1, max_size=6), cols=st.sampled_from([1, 7, 4096, 8960, 8961, 70_001, 1 << 19]),
+@given(runs=st.lists(row_run, min_size=1, max_size=6), cols=st.sampled_from([1, 7, 4096, 8960, 8961, 9472, 9473, 70_001, 1 << 19]),
        local=st.booleans(), seed=st.integers(0, 2**31 - 1))
 def test_wave_pipe_random_structures(pkg, oracle, gpu, runs, cols, local, seed):
     """Row lengths around the thresholds (a wavefront, a run's 512, a piece's 1024), runs of empty rows, rows that fill
@@ -88,11 +95,18 @@ def test_wave_pipe_random_structures(pkg, oracle, gpu, runs, cols, local, seed):
     ci = ci.astype(np.int32)
     va = rng.uniform(-1, 1, size=nnz).astype(np.float32)
     x = rng.uniform(-1, 1, size=cols).astype(np.float32)
-    prob = DeviceProblem(pkg, gpu, rows, cols, rp, ci, va, x)
-    y = prob.run(pkg.capi.WAVE_PIPE)
+    import os
+    os.environ["SPMV_WAVE_BLOCK"] = ["512", "1024"][seed % 2]
+    try:
+        prob = DeviceProblem(pkg, gpu, rows, cols, rp, ci, va, x)
+        y = prob.run(pkg.capi.WAVE_PIPE)
+        ys = prob.run(pkg.capi.SCALAR)          # the same kernel with ordered sums: bit-identical to the sequential oracle
+    finally:
+        del os.environ["SPMV_WAVE_BLOCK"]
     assert not np.isnan(y).any(), "rows left unwritten"
     y64, mag = oracle.spmv_f64(rp, ci, va, x)
     assert_close_to_oracle(y, y64, mag, "wave_pipe")
+    assert np.array_equal(ys.view(np.uint32), oracle.spmv(rp, ci, va, x).view(np.uint32)), "scalar is not bit-identical"
     prob.A.close()
 
 
