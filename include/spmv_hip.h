@@ -55,13 +55,22 @@ enum spmv_status {
 enum spmv_variant {
     SPMV_SCALAR = 0,    /* thread per row, k ascending, mul+add unfused:           */
                         /*   csr_naive_kernel      src/kernels/csr_naive.cu:6-23   */
-                        /*   (bit-identical to SgemvCPU, src/tester.cpp:36-45)     */
+                        /*   (bit-identical to SgemvCPU, src/tester.cpp:36-45).    */
+                        /* Shares SPMV_WAVE_PIPE's plan (operands only; see there). */
     SPMV_WAVE = 1,      /* one 64-lane wavefront per row, __shfl_down reduction:   */
                         /*   wsp_kernel_v0         src/kernels/wsp.cu:4-56         */
     SPMV_WAVE_PIPE = 2, /* a wavefront per 64 rows: their nonzeros streamed        */
-                        /* coalesced, products parked in LDS, a lane per short row, */
-                        /* the wave + __shfl_down per long row (4 loads in flight): */
+                        /* coalesced with all loads of a run in flight, products    */
+                        /* parked in LDS, a lane per short row, the wave +          */
+                        /* __shfl_down per longer one; rows of more than 512        */
+                        /* nonzeros in pieces, a wavefront per piece; x from a      */
+                        /* window in LDS per block of rows where the columns fit:   */
                         /*   wsp_kernel_v1         src/kernels/wsp.cu:59-138       */
+                        /* Plan: the long rows and the windows, a function of       */
+                        /* row_ptr and col_idx (NOT of the values).  A handle that  */
+                        /* was not planned plans on its first run (allocates and    */
+                        /* waits for the stream once: call spmv_csr_plan before     */
+                        /* capturing a graph).                                      */
     SPMV_VECTOR = 3,    /* 2..32-lane groups per row, width from mean row length:  */
                         /*   asp_kernel_v0/1/2     src/kernels/asp.cu:6-211        */
     SPMV_ADAPTIVE = 4,  /* nnz-balanced chunks, products staged in LDS, per-chunk  */
