@@ -370,7 +370,8 @@ def main():
             dom_kernel = ("k_tiled16" if _n("col16_chunks") == _n("chunks") else
                           "k_sorted" if _n("sorted_chunks") == _n("chunks") else "k_tiled_mixed")
         else:
-            dom_kernel = "k_adaptive" if resolved in ("adaptive", "tiled") else f"k_{resolved}"
+            dom_kernel = ("k_adaptive" if resolved in ("adaptive", "tiled") else
+                          "k_wave_bundle" if "block_rows=" in plan_now else f"k_{resolved}")
         out = {
             "metric": "fp32 CSR SpMV throughput in CSR-algorithmic bytes per second (8/nnz + row_ptr + x + y over time; "
                       "roofline.frac_hbm_counters is the FETCH_SIZE/WRITE_SIZE-based figure)",

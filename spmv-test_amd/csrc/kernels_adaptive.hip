@@ -58,7 +58,11 @@ __host__ __device__ constexpr int max_long(int block) { return chunk_of(block) /
 constexpr int kHugeSeg = SPMV_T_HUGE;  // segments longer than this are summed by one wavefront each
 __host__ __device__ constexpr int max_huge(int block) { return chunk_of(block) / (kHugeSeg + 1) + 2; }
 
+#ifdef SPMV_T_NOPAD   // (A/B builds only)
+__device__ __forceinline__ int pad_idx(int i) { return i; }
+#else
 __device__ __forceinline__ int pad_idx(int i) { return i + (i >> 5); }
+#endif
 
 // chunk handled by this block: XCD j = blockIdx % 8 gets a contiguous range
 __device__ __forceinline__ int xcd_chunk(int bid, int n)

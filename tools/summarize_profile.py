@@ -66,8 +66,16 @@ def main():
         kernels[k] = {"launches": n, "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
                       "hbm_bytes_per_launch": int(round((2 * f_kib + w_kib) * 1024))}
     # the plan autotunes over several instantiations of k_adaptive: the timed one has the most launches
-    hot = ("k_panel(", "k_colsort") if variant == "panel" else ("k_adaptive", "k_tiled16", "k_tiled_mixed", "k_sorted")
+    hot = (("k_panel(", "k_colsort") if variant == "panel" else
+           ("k_wave_bundle",) if variant in ("wave_pipe", "scalar") else
+           ("k_adaptive", "k_tiled16", "k_tiled_mixed", "k_sorted"))
     dom = max((k for k in kernels if any(h in k for h in hot)), key=lambda k: kernels[k]["launches"])
+    if variant == "wave_pipe":      # one SpMV = bundles + pieces + combine: the counters of all three
+        for k in kernels:
+            if k != dom and ("k_wave_pieces" in k or "k_wave_combine" in k):
+                for key in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_per_launch"):
+                    kernels[dom][key] = kernels[dom][key] + kernels[k][key]
+        kernels[dom]["note"] = "counters of k_wave_bundle + k_wave_pieces + k_wave_combine: one SpMV"
     # the panel sweep covers the matrix in several launches of the same kernel ("launches=N" in the plan string):
     # scale the per-launch counters to one SpMV so they compare with the algorithmic bytes of one SpMV
     per_spmv = 1
