@@ -63,6 +63,16 @@ __device__ __forceinline__ int pad_idx(int i) { return i; }
 #else
 __device__ __forceinline__ int pad_idx(int i) { return i + (i >> 5); }
 #endif
+// The pad words themselves (slot 32 of every 33) hold 0.0f while the products are in LDS: the row sums then walk the PADDED
+// positions [pad_idx(s), pad_idx(e)) of a segment with constant offsets -- no index arithmetic per product, the holes add
+// +0.0 (round 3: two vector instructions per LDS read less; the kernel's vector units were busy two thirds of its time).
+template <int BLOCK>
+__device__ __forceinline__ void zero_pad_words(float *smem, int tid)
+{
+#ifndef SPMV_T_NOPAD
+    for (int h = tid; h < (chunk_of(BLOCK) >> 5); h += BLOCK) smem[h * 33 + 32] = 0.0f;
+#endif
+}
 
 // chunk handled by this block: XCD j = blockIdx % 8 gets a contiguous range
 __device__ __forceinline__ int xcd_chunk(int bid, int n)
@@ -319,22 +329,24 @@ __device__ __forceinline__ void reduce_chunk(const float *smem, ChunkShared<BLOC
         if (PREF && t == tid) { rb = rb0; re = re0; }
         else { rb = row_ptr[t == 0 ? lb0 : lb0 + t - 1]; re = t == 0 ? 0 : row_ptr[lb0 + t]; }
         const Segment g = make_segment(t, lb0, base, lim, rb, re, y, carry, c);
+        const int ps = pad_idx(g.s), pe = pad_idx(g.e);     // the segment's words in LDS, pad words (zeros) included
         if (g.e - g.s <= kShortSeg) {
             float acc = 0.0f;
-            int i = g.s;
-            for (; i + 3 < g.e; i += 4) {
-                const float a0 = smem[pad_idx(i)], a1 = smem[pad_idx(i + 1)], a2 = smem[pad_idx(i + 2)],
-                            a3 = smem[pad_idx(i + 3)];
+            const float *w = smem + ps;
+            int i = 0;
+            const int n = pe - ps;
+            for (; i + 3 < n; i += 4) {
+                const float a0 = w[i], a1 = w[i + 1], a2 = w[i + 2], a3 = w[i + 3];
                 acc = (((acc + a0) + a1) + a2) + a3;
             }
-            for (; i < g.e; ++i) acc += smem[pad_idx(i)];
+            for (; i < n; ++i) acc += w[i];
             *g.dst = acc;
         } else if (g.e - g.s <= kHugeSeg) {
             const int slot = atomicAdd(&sh.long_count, 1);
-            sh.long_seg[slot] = make_int2(t, g.s | (g.e << 16));  // s < 2^14, e <= 2^14
+            sh.long_seg[slot] = make_int2(t, ps | (pe << 16));  // both below 2^15
         } else {
             const int slot = atomicAdd(&sh.huge_count, 1);
-            sh.huge_seg[slot] = make_int2(t, g.s | (g.e << 16));
+            sh.huge_seg[slot] = make_int2(t, ps | (pe << 16));
         }
     }
     __syncthreads();
@@ -345,7 +357,7 @@ __device__ __forceinline__ void reduce_chunk(const float *smem, ChunkShared<BLOC
         const int2 q = sh.long_seg[i];
         const int qe = (int)((unsigned)q.y >> 16);
         float acc = 0.0f;
-        for (int k = (q.y & 0xffff) + sub; k < qe; k += kGroup) acc += smem[pad_idx(k)];
+        for (int k = (q.y & 0xffff) + sub; k < qe; k += kGroup) acc += smem[k];
 #pragma unroll
         for (int o = kGroup / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kGroup);
         if (sub == 0) {
@@ -365,10 +377,10 @@ __device__ __forceinline__ void reduce_chunk(const float *smem, ChunkShared<BLOC
         float a0 = 0.0f, a1 = 0.0f;
         int k = (q.y & 0xffff) + lane;
         for (; k + kWave < qe; k += 2 * kWave) {
-            a0 += smem[pad_idx(k)];
-            a1 += smem[pad_idx(k + kWave)];
+            a0 += smem[k];
+            a1 += smem[k + kWave];
         }
-        if (k < qe) a0 += smem[pad_idx(k)];
+        if (k < qe) a0 += smem[k];
         float acc = a0 + a1;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
@@ -597,6 +609,7 @@ __device__ __forceinline__ void adaptive_body(float *smem, ChunkShared<BLOCK> &s
         }
 
         // ---- stage the products (padded one word per 32: lane-per-row reads spread over banks)
+        zero_pad_words<BLOCK>(smem, tid);
 #pragma unroll
         for (int j = 0; j < kVec; ++j) {
             const int p0 = pad_idx((j * BLOCK + tid) * 4);  // i0 % 4 == 0: never straddles a pad slot
@@ -703,6 +716,23 @@ __device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh
     for (int j = 0; j < kVec; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) xv[j][q] = 0.0f;
+#ifndef SPMV_T_NOSTAGE
+    if (wlen <= kRegion && wlen > 0) {
+        // one pass (nearly every chunk): every offset lies inside the staged window, no range check per element
+        if (by_blocks) stage_blocks<BLOCK>(x, blk + (int64_t)c * kBlkMax, wlen / kBlkCols, cols, smem, tid);
+        else stage_slice<BLOCK, true>(x, (int64_t)w0, wlen, cols, smem, tid);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kVec; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = (j & 1) * 4 + q;
+                const unsigned word = raw[j >> 1][e >> 1];
+                xv[j][q] = smem[(e & 1) ? (word >> 16) : (word & 0xffffu)];
+            }
+        __syncthreads();  // every gather has its value before the products overwrite the window
+    } else
+#endif
 #ifdef SPMV_T_NOSTAGE   // (A/B builds only: the kernel without its x window -- results are wrong)
     for (int off = 0; off < 0; off += kRegion) {
 #else
@@ -728,6 +758,7 @@ __device__ __forceinline__ void tiled16_body(float *smem, ChunkShared<BLOCK> &sh
     }
 
     // ---- products, then the rows of the chunk
+    zero_pad_words<BLOCK>(smem, tid);
 #pragma unroll
     for (int j = 0; j < kVec; ++j) {
         const int p0 = pad_idx((j * BLOCK + tid) * 4);
@@ -823,6 +854,7 @@ __device__ __forceinline__ void sorted_body(float *smem, ChunkShared<BLOCK> &sh,
     }
     __syncthreads();
     // this lane's values meet their x; the products take the same LDS words
+    zero_pad_words<BLOCK>(smem, tid);
 #pragma unroll
     for (int j = 0; j < kVec; ++j) {
         const int p0 = pad_idx((j * BLOCK + tid) * 4);
