@@ -232,6 +232,16 @@ constexpr int64_t kWaveBigRows = 2 << 20;
 constexpr int kPieceLen = SPMV_PIECE_LEN;          // nonzeros of a piece of a long row (one wavefront of k_wave_pieces)
 static_assert(kBundleCap % (4 * kWave) == 0 && wave_window(512) % 32 == 0 && wave_window(1024) % 32 == 0, "bundle geometry");
 
+// Workgroups are dealt round-robin over the 8 XCDs: block b of the grid takes work item xcd_item(b, n), so that every XCD
+// gets ONE contiguous range of the n items -- neighbouring blocks of rows share lines of x, and a contiguous eighth of a
+// banded matrix keeps its part of x in that XCD's 4 MiB of L2 (bijective for any n).
+__device__ __forceinline__ int xcd_item(int bid, int n)
+{
+    const int q = n / kXcds, rem = n % kXcds;
+    const int j = bid % kXcds, idx = bid / kXcds;
+    return j * q + (j < rem ? j : rem) + idx;
+}
+
 // Buffer descriptors (wave-uniform base in scalar registers, 32-bit lane offsets, immediate slice offsets, reads past the
 // end return 0): the streamed loads of a run share ONE offset register and need no predicates, and a gather's address is
 // the column itself.
@@ -344,14 +354,15 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
     const int wave = threadIdx.x >> 6;
     float *prod = prod_all[MODE == 2 ? 0 : wave];
     const __amdgpu_buffer_rsrc_t xr = rsrc_of(x, x_bytes);
-    const int64_t r0 = ((int64_t)blockIdx.x * kWaves + wave) * kWave;
+    const int blk = xcd_item((int)blockIdx.x, (int)gridDim.x);          // this workgroup's block of BLOCK rows
+    const int64_t r0 = ((int64_t)blk * kWaves + wave) * kWave;
     const int64_t r = r0 + lane;
     const bool live = r < rows;
     const int32_t b = row_ptr[live ? r : rows], e = row_ptr[live ? r + 1 : rows];
     const int n = r0 < rows ? (int)((rows - r0 < kWave) ? rows - r0 : kWave) : 0;
     const unsigned long long long_mask = __ballot(e - b > kBundleCap);     // k_wave_pieces' rows
     int32_t lo = -1;
-    if (MODE == 1) lo = __builtin_amdgcn_readfirstlane(blk_lo[blockIdx.x]);
+    if (MODE == 1) lo = __builtin_amdgcn_readfirstlane(blk_lo[blk]);
     const float *win = (MODE == 1 && lo >= 0) ? win_lds : nullptr;
 
     // the next run: the rows from `from` on that are not long and hold at most kBundleCap nonzeros together
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
                 w = cmin & ~31;
                 if (cmax - w >= kWindow) w = -1;
             }
-            blk_lo[blockIdx.x] = w;
+            blk_lo[blk] = w;
         }
     }
 }
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_pieces(int npieces, uint32_t x_
 {
     constexpr int S = kPieceLen / kWave;
     const int lane = threadIdx.x & (kWave - 1);
-    const int p = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int p = xcd_item((int)blockIdx.x, (int)gridDim.x) * (kBlock / kWave) + (threadIdx.x >> 6);
     if (p >= npieces) return;   // wave-uniform
     const __amdgpu_buffer_rsrc_t xr = rsrc_of(x, x_bytes);
     const int32_t k0 = __builtin_amdgcn_readfirstlane(piece_k0[p]), len = __builtin_amdgcn_readfirstlane(piece_len[p]);
