@@ -316,20 +316,20 @@ __device__ __forceinline__ void bundle_multiply(int lane, int32_t len, __amdgpu_
     }
 }
 
-// the workgroup's window: entries [lo, lo + wave_window(BLOCK)) of x into LDS (zeros past the end of x)
+// the workgroup's window: entries [lo, lo + wave_window(BLOCK)) of x into LDS (zeros past the end of x).  LDS-DMA
+// (global_load_lds_dwordx4: no register in between, every 16-byte piece of a lane in flight at once), issued before the
+// wave waits for its row pointers.
 template <int BLOCK>
 __device__ __forceinline__ void load_window(float *win, const float *__restrict__ x, int64_t lo, int64_t cols)
 {
-    for (int i = threadIdx.x * 4; i < wave_window(BLOCK); i += BLOCK * 4) {
-        const int64_t g = lo + i;
-        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (g + 3 < cols) q = *reinterpret_cast<const float4 *>(x + g);
-        else {
-            if (g < cols) q.x = x[g];
-            if (g + 1 < cols) q.y = x[g + 1];
-            if (g + 2 < cols) q.z = x[g + 2];
+    if (lo + wave_window(BLOCK) + 3 < cols) {      // workgroup-uniform
+        for (int i = threadIdx.x * 4; i < wave_window(BLOCK); i += BLOCK * 4)
+            __builtin_amdgcn_global_load_lds(x + lo + i, win + i, 16, 0, 0);
+    } else {
+        for (int i = threadIdx.x * 4; i < wave_window(BLOCK); i += BLOCK * 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) win[i + q] = lo + i + q < cols ? x[lo + i + q] : 0.0f;
         }
-        *reinterpret_cast<float4 *>(win + i) = q;
     }
 }
 
@@ -360,10 +360,11 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
     const bool live = r < rows;
     const int32_t b = row_ptr[live ? r : rows], e = row_ptr[live ? r + 1 : rows];
     const int n = r0 < rows ? (int)((rows - r0 < kWave) ? rows - r0 : kWave) : 0;
-    const unsigned long long long_mask = __ballot(e - b > kBundleCap);     // k_wave_pieces' rows
     int32_t lo = -1;
     if (MODE == 1) lo = __builtin_amdgcn_readfirstlane(blk_lo[blk]);
     const float *win = (MODE == 1 && lo >= 0) ? win_lds : nullptr;
+    if (MODE == 1 && win) load_window<BLOCK>(win_lds, x, lo, cols);        // (needs blk_lo only: out before b / e are waited for)
+    const unsigned long long long_mask = __ballot(e - b > kBundleCap);     // k_wave_pieces' rows
 
     // the next run: the rows from `from` on that are not long and hold at most kBundleCap nonzeros together
     int i0 = 0, i1 = 0;
@@ -384,10 +385,7 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
     float v[kBundleSlices];
     next_run(0);
     bundle_loads(lane, sb, len, col_idx, vals, c, v);
-    if (MODE == 1) {
-        if (win) load_window<BLOCK>(win_lds, x, lo, cols);
-        __syncthreads();
-    }
+    if (MODE == 1) __syncthreads();         // the window has landed
     int32_t cmin = 0x7fffffff, cmax = -1;
     while (i0 < n) {
         if (MODE == 2) {
