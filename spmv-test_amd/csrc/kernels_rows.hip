@@ -214,7 +214,9 @@ __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__
 // without a plan from sampled columns (two more round trips in every workgroup), the pieces inside the bundle kernel
 // (0.44 ms: its LDS leaves three workgroups per CU, too few loads in flight for the pieces), a window per long row (the
 // synthetic band law gives a row of n nonzeros 8n columns: as many bytes of windows as of matrix), the pieces on a second
-// stream beside the bundles (no overlap: 0.386 against 0.382 ms).
+// stream beside the bundles (no overlap: 0.386 against 0.382 ms), 16-bit offsets into the window in a pair layout (a lane
+// holds two consecutive nonzeros, 6 bytes per nonzero: config 2 0.0317 -> 0.0303 ms, but config 3 0.358 -> 0.374 and config
+// 4 0.614 -> 0.640; with the runs aligned to even nonzeros config 2 fell to 0.040).
 #ifndef SPMV_BUNDLE_CAP
 #define SPMV_BUNDLE_CAP 512
 #endif
