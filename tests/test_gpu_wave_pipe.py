@@ -157,3 +157,36 @@ def test_wave_pipe_edge_shapes(pkg, oracle, gpu):
             y64, mag = oracle.spmv_f64(rp, ci, va, x)
             assert_close_to_oracle(y, y64, mag, f"wave_pipe {rows}x{cols}")
         prob.A.close()
+
+
+def test_wave_pipe_x_beyond_a_buffer_descriptor(pkg, oracle, gpu):
+    """x of 2^30 + 7 entries (4 GiB): past what a 32-bit descriptor addresses, so the kernels take their plain-load
+    instantiations (k_wave_bundle<false, ...>, k_wave_pieces<false>).  Rows with local columns (blocks with a window), rows
+    with columns anywhere, rows on either side of the run and piece lengths."""
+    import torch
+    capi = pkg.capi
+    cols = (1 << 30) + 7
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(0, 24, size=3000)
+    for r, L in ((10, 511), (11, 512), (700, 1025), (1900, 5000), (2999, 700)):
+        lengths[r] = L
+    rows = len(lengths)
+    rp = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    nnz = int(rp[-1])
+    rows_of = np.repeat(np.arange(rows), lengths)
+    local = (cols - 9000) + (rows_of % 4000) + rng.integers(0, 4000, size=nnz)      # a window at the far end of x
+    anywhere = rng.integers(0, cols, size=nnz)
+    ci = np.where(rows_of < 1024, local, anywhere).astype(np.int32)                  # the first blocks local, the rest not
+    va = rng.uniform(-1, 1, size=nnz).astype(np.float32)
+    x = np.zeros(cols, np.float32)
+    x[ci] = rng.uniform(-1, 1, size=nnz).astype(np.float32)
+    prob = DeviceProblem(pkg, gpu, rows, cols, rp, ci, va, x)
+    y = prob.run(capi.WAVE_PIPE)
+    ys = prob.run(capi.SCALAR)
+    assert not np.isnan(y).any()
+    y64, mag = oracle.spmv_f64(rp, ci, va, x)
+    assert_close_to_oracle(y, y64, mag, "wave_pipe, 4 GiB x")
+    assert np.array_equal(ys.view(np.uint32), oracle.spmv(rp, ci, va, x).view(np.uint32)), "scalar is not bit-identical"
+    prob.A.close()
+    del prob
+    torch.cuda.empty_cache()
