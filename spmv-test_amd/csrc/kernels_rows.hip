@@ -1,19 +1,20 @@
 // kernels_rows.hip -- row-mapped CSR SpMV kernels for gfx950 (wave64).
 //
-//   k_scalar   thread per row, sequential, unfused mul+add (operands staged by the workgroup)
-//              role of csr_naive_kernel (/root/reference/src/kernels/csr_naive.cu:6-23);
-//              the same per-row operation order as SgemvCPU (src/tester.cpp:36-45),
-//              so results are bit-identical to the CPU oracle.
+//   SPMV_SCALAR  a lane per row, terms added in ascending k, unfused mul+add: role of csr_naive_kernel
+//              (/root/reference/src/kernels/csr_naive.cu:6-23); the same per-row operation order as SgemvCPU
+//              (src/tester.cpp:36-45), so results are bit-identical to the CPU oracle.  Mean rows of up to 32 nonzeros:
+//              k_wave_bundle<..., ORDERED> (below); up to 64: k_scalar (the workgroup's rows staged through LDS); longer:
+//              k_scalar_long (a wavefront per row, readlane chain).
 //   k_wave     one 64-lane wavefront per row, lanes stride the row, __shfl_down tree
 //              role of wsp_kernel_v0 (src/kernels/wsp.cu:4-56): "one warp per output,
 //              butterfly reduce, lane 0 stores" -- re-derived for CSR and 64 lanes.
-//   k_wave_bundle  a wavefront per 64 consecutive rows: coalesced stream of their nonzeros,
-//              products parked in LDS, lane per short row, whole wave per long row
-//              role of wsp_kernel_v1 (src/kernels/wsp.cu:59-138), the reference's pipelined version.
+//   k_wave_bundle + k_wave_pieces + k_wave_combine (SPMV_WAVE_PIPE)  a wavefront per 64 consecutive rows: coalesced
+//              streams at full depth, products parked in LDS, x from a window in LDS, long rows in pieces for the whole
+//              chip: role of wsp_kernel_v1 (src/kernels/wsp.cu:59-138), the reference's pipelined version.
 //   k_vector   G-lane groups per row (G = 2..32), the short-row member of the family
 //              role of asp_kernel_v* (src/kernels/asp.cu:6-211: many outputs per block).
 //
-// All three are HBM/gather bound: no LDS, no MFMA (0.25 flop/byte).
+// No MFMA anywhere (0.25 flop/byte): streams, gathers, LDS.
 #include <cstdlib>
 #include <vector>
 #include "spmv_internal.hpp"
