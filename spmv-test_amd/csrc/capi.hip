@@ -522,7 +522,7 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
             if (panel.sorted_mode)   // unit bases, block tables, the rows of the tail units, the empty slots of the units in use
                 return panel.units * 4 + (int64_t)panel.nblocks * 20 + panel.tail_units * 512;
             return (int64_t)panel.nblocks * (panel.npanels + 1) * 4 + ((int64_t)panel.nblocks + 1) * 4;
-        case SPMV_WAVE_PIPE: // the long rows' list, piece table read, partial sums written and re-read
+        case SPMV_WAVE_PIPE: // the long rows' list, piece table read, partial sums written and re-read (col16 REPLACES 4 of col_idx's bytes with 2)
             return (int64_t)h->plan_wave.n_long * 8 + (int64_t)h->plan_wave.pieces * 16 + h->plan_wave.blocks * 8;
         default: return 0;
     }
@@ -546,8 +546,9 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
     if (variant == SPMV_VECTOR) snprintf(buf, (size_t)n, "lanes_per_row=%d", h->vector_width);
     else if (variant == SPMV_WAVE_PIPE || variant == SPMV_SCALAR) {
         if (!h->plan_wave.ready) snprintf(buf, (size_t)n, "not planned (the first run plans)");
-        else snprintf(buf, (size_t)n, "long_rows=%d pieces=%d block_rows=%d blocks=%lld blocks_with_x_window=%lld", h->plan_wave.n_long,
-                      h->plan_wave.pieces, h->plan_wave.block_rows, (long long)h->plan_wave.blocks, (long long)h->plan_wave.win_blocks);
+        else snprintf(buf, (size_t)n, "long_rows=%d pieces=%d block_rows=%d blocks=%lld blocks_with_x_window=%lld col16=%d", h->plan_wave.n_long,
+                      h->plan_wave.pieces, h->plan_wave.block_rows, (long long)h->plan_wave.blocks, (long long)h->plan_wave.win_blocks,
+                      h->plan_wave.d_col16 ? 1 : 0);
     }
     else if (variant == SPMV_PANEL && panel->ready && panel->sorted_mode)
         snprintf(buf, (size_t)n, "sorted_blocks=%d rows_per_block=%d wavefronts=%d lines_per_nonzero=%.3f tail_nonzeros=%lld wide_blocks=%lld model_cost=%.3f",

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__
 //     adds a row's pieces in order.
 //   * x comes from a window in LDS -- the entries [lo, lo + wave_window) that hold every column of the block's rows
 //     (the long ones excepted: theirs are gathered from memory), found by the plan -- where such a window exists, else
-//     from memory.
+//     from memory; the columns of a windowed block are read as the plan's 16-bit offsets into the window (6 bytes per
+//     nonzero instead of 8).
 // The plan is a function of row_ptr and col_idx (not of the values), made by spmv_csr_plan or by the first run.
 // Round 3's A/Bs (profiles/r03_rows_bounds.jsonl; config 3 with band 8192, 0.759 ms before, 0.386 ms now): the longest rows
 // -- 65 536 nonzeros on ONE wavefront, 256 dependent trips -- were 0.40 ms of it; with the streams at full depth (0.16 ms
@@ -215,9 +216,10 @@ __global__ __launch_bounds__(kBlock) void k_wave(int64_t rows, const int32_t *__
 // without a plan from sampled columns (two more round trips in every workgroup), the pieces inside the bundle kernel
 // (0.44 ms: its LDS leaves three workgroups per CU, too few loads in flight for the pieces), a window per long row (the
 // synthetic band law gives a row of n nonzeros 8n columns: as many bytes of windows as of matrix), the pieces on a second
-// stream beside the bundles (no overlap: 0.386 against 0.382 ms), 16-bit offsets into the window in a pair layout (a lane
-// holds two consecutive nonzeros, 6 bytes per nonzero: config 2 0.0317 -> 0.0303 ms, but config 3 0.358 -> 0.374 and config
-// 4 0.614 -> 0.640; with the runs aligned to even nonzeros config 2 fell to 0.040).
+// stream beside the bundles (no overlap: 0.386 against 0.382 ms), the 16-bit offsets in a PAIR layout (a lane holds two
+// consecutive nonzeros, 8-byte loads of values: config 2 0.0317 -> 0.0303 ms, but config 3 0.358 -> 0.374 and config 4
+// 0.614 -> 0.640; with the runs aligned to even nonzeros config 2 fell to 0.040) -- in the slice layout the same offsets
+// gain everywhere (config 2 0.0320 -> 0.0304, config 3 0.356 -> 0.350, config 4 0.618 -> 0.588) and are what ships.
 #ifndef SPMV_BUNDLE_CAP
 #define SPMV_BUNDLE_CAP 512
 #endif
@@ -292,6 +294,30 @@ __device__ __forceinline__ void bundle_loads(int lane, int64_t k0, int32_t len, 
         }
     }
 }
+// the same with the columns as the plan's 16-bit offsets into the block's window (2 bytes per nonzero instead of 4):
+// c[u] = offset of nonzero k0 + u*64 + lane (0 past the end)
+template <int S>
+__device__ __forceinline__ void bundle_loads16(int lane, int64_t k0, int32_t len, const uint16_t *__restrict__ col16,
+                                               const float *__restrict__ vals, int32_t (&c)[S], float (&v)[S])
+{
+    const __amdgpu_buffer_rsrc_t cr = rsrc_of(uniform_ptr(col16 + k0), (uint32_t)len * 2u);
+    const __amdgpu_buffer_rsrc_t vr = rsrc_of(uniform_ptr(vals + k0), (uint32_t)len * 4u);
+    int lane2 = lane * 2, lane4 = lane * 4;
+    asm volatile("" : "+v"(lane2), "+v"(lane4));
+#pragma unroll
+    for (int t = 0; t < S; t += 4) {
+        if (t * kWave < len) {
+#pragma unroll
+            for (int u = t; u < t + 4; ++u) {
+                c[u] = (int32_t)__builtin_amdgcn_raw_buffer_load_b16(cr, lane2 + u * (kWave * 2), 0, 0);
+                v[u] = buf_f32(vr, lane4 + u * (kWave * 4));
+            }
+        } else {
+#pragma unroll
+            for (int u = t; u < t + 4; ++u) { c[u] = 0; v[u] = 0.0f; }
+        }
+    }
+}
 // v[u] *= x[c[u]]: from the window in LDS (win: entries [lo, lo + wlast] of x, every column of the caller's rows
 // inside it -- the plan checked) or from memory, through a descriptor when x is shorter than 4 GiB (BUFX), else plain loads
 template <bool BUFX, int S>
@@ -310,7 +336,7 @@ __device__ __forceinline__ void bundle_multiply(int lane, int32_t len, __amdgpu_
 #else
                 const int32_t cc = c[t + u];
 #endif
-                if (win) xv[u] = win[min((uint32_t)(cc - lo), wlast)];   // (slots past the end hold column 0)
+                if (win) xv[u] = win[min((uint32_t)(cc - lo), wlast)];   // (slots past the end hold column 0; lo = 0: cc is an offset)
                 else xv[u] = BUFX ? buf_f32(xr, cc << 2) : x[cc];
             }
 #pragma unroll
@@ -346,16 +372,17 @@ template <bool BUFX, int BLOCK, int MODE, bool ORDERED>
 __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t cols, uint32_t x_bytes,
                                                        const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
                                                        const float *__restrict__ vals, const float *__restrict__ x,
-                                                       float *__restrict__ y, int32_t *__restrict__ blk_lo)
+                                                       float *__restrict__ y, int32_t *__restrict__ blk_lo,
+                                                       uint16_t *__restrict__ col16)
 {
     constexpr int kWaves = BLOCK / kWave;
-    __shared__ float prod_all[MODE == 2 ? 1 : kWaves][MODE == 2 ? 1 : kBundleCap];
+    __shared__ float prod_all[MODE >= 2 ? 1 : kWaves][MODE >= 2 ? 1 : kBundleCap];
     constexpr int kWindow = wave_window(BLOCK);
     __shared__ __attribute__((aligned(16))) float win_lds[MODE == 1 ? kWindow : 4];
     __shared__ int32_t smin[kWaves], smax[kWaves];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    float *prod = prod_all[MODE == 2 ? 0 : wave];
+    float *prod = prod_all[MODE >= 2 ? 0 : wave];
     const __amdgpu_buffer_rsrc_t xr = rsrc_of(x, x_bytes);
     const int blk = xcd_item((int)blockIdx.x, (int)gridDim.x);          // this workgroup's block of BLOCK rows
     const int64_t r0 = ((int64_t)blk * kWaves + wave) * kWave;
@@ -364,7 +391,7 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
     const int32_t b = row_ptr[live ? r : rows], e = row_ptr[live ? r + 1 : rows];
     const int n = r0 < rows ? (int)((rows - r0 < kWave) ? rows - r0 : kWave) : 0;
     int32_t lo = -1;
-    if (MODE == 1) lo = __builtin_amdgcn_readfirstlane(blk_lo[blk]);
+    if (MODE == 1 || MODE == 3) lo = __builtin_amdgcn_readfirstlane(blk_lo[blk]);
     const float *win = (MODE == 1 && lo >= 0) ? win_lds : nullptr;
     if (MODE == 1 && win) load_window<BLOCK>(win_lds, x, lo, cols);        // (needs blk_lo only: out before b / e are waited for)
     const unsigned long long long_mask = __ballot(e - b > kBundleCap);     // k_wave_pieces' rows
@@ -386,8 +413,14 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
     };
     int32_t c[kBundleSlices];
     float v[kBundleSlices];
+    // a block with a window reads the plan's 16-bit offsets into it (MODE 1); everything else the 32-bit columns
+    const bool off16 = MODE == 1 && win != nullptr && col16 != nullptr;
+    auto run_loads = [&]() {
+        if (off16) bundle_loads16(lane, sb, len, col16, vals, c, v);
+        else bundle_loads(lane, sb, len, col_idx, vals, c, v);
+    };
     next_run(0);
-    bundle_loads(lane, sb, len, col_idx, vals, c, v);
+    run_loads();
     if (MODE == 1) __syncthreads();         // the window has landed
     int32_t cmin = 0x7fffffff, cmax = -1;
     while (i0 < n) {
@@ -397,10 +430,20 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
                 if (u * kWave + lane < len) { cmin = min(cmin, c[u]); cmax = max(cmax, c[u]); }
             }
             next_run(i1);
-            bundle_loads(lane, sb, len, col_idx, vals, c, v);
+            run_loads();
             continue;
         }
-        bundle_multiply<BUFX, kBundleSlices>(lane, len, xr, x, win, lo, (uint32_t)(kWindow - 1), c, v);
+        if (MODE == 3) {        // the block's offsets into its window, where it has one
+            if (lo >= 0) {
+#pragma unroll
+                for (int u = 0; u < kBundleSlices; ++u)
+                    if (u * kWave + lane < len) col16[(int64_t)sb + u * kWave + lane] = (uint16_t)(c[u] - lo);
+            }
+            next_run(i1);
+            run_loads();
+            continue;
+        }
+        bundle_multiply<BUFX, kBundleSlices>(lane, len, xr, x, win, off16 ? 0 : lo, (uint32_t)(kWindow - 1), c, v);
 #pragma unroll
         for (int t = 0; t < kBundleSlices; t += 4) {
             if (t * kWave < len) {
@@ -412,7 +455,7 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
         const int a0 = i0, a1 = i1;
         const int32_t asb = sb;
         next_run(a1);
-        bundle_loads(lane, sb, len, col_idx, vals, c, v);
+        run_loads();
         const bool mine = lane >= a0 && lane < a1;
         const bool is_long = mine && e - b > kWave;
         if (mine && !is_long) {
@@ -463,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
         // (the next run's products overwrite prod only after every lane of this wave is past its reads: one wave,
         // program order)
     }
-    if (ORDERED && MODE != 2) {
+    if (ORDERED && MODE < 2) {
         unsigned long long todo = long_mask;
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
@@ -642,25 +685,28 @@ void destroy_wave(WavePlan &p)
     (void)hipFree(p.d_piece_len);
     (void)hipFree(p.d_partial);
     (void)hipFree(p.d_blk_lo);
+    (void)hipFree(p.d_col16);
     p = WavePlan{};
 }
 
 template <int MODE, bool ORDERED, int BLOCK>
-static void launch_bundle_block(const spmv_csr &h, const WavePlan &p, const float *x, float *y, int32_t *blk_lo, hipStream_t s)
+static void launch_bundle_block(const spmv_csr &h, const WavePlan &p, const float *x, float *y, int32_t *blk_lo, uint16_t *col16,
+                                hipStream_t s)
 {
     const dim3 grid((unsigned)p.blocks);
     if (h.cols < (1LL << 30))
         hipLaunchKernelGGL((k_wave_bundle<true, BLOCK, MODE, ORDERED>), grid, dim3(BLOCK), 0, s, h.rows, h.cols,
-                           (uint32_t)(h.cols * 4), h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, blk_lo);
+                           (uint32_t)(h.cols * 4), h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, blk_lo, col16);
     else
         hipLaunchKernelGGL((k_wave_bundle<false, BLOCK, MODE, ORDERED>), grid, dim3(BLOCK), 0, s, h.rows, h.cols, 0u,
-                           h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, blk_lo);
+                           h.d_row_ptr, h.d_col_idx, h.d_vals, x, y, blk_lo, col16);
 }
 template <int MODE, bool ORDERED = false>
-static void launch_bundle(const spmv_csr &h, const WavePlan &p, const float *x, float *y, int32_t *blk_lo, hipStream_t s)
+static void launch_bundle(const spmv_csr &h, const WavePlan &p, const float *x, float *y, int32_t *blk_lo, uint16_t *col16,
+                          hipStream_t s)
 {
-    if (p.block_rows == 1024) launch_bundle_block<MODE, ORDERED, 1024>(h, p, x, y, blk_lo, s);
-    else launch_bundle_block<MODE, ORDERED, 512>(h, p, x, y, blk_lo, s);
+    if (p.block_rows == 1024) launch_bundle_block<MODE, ORDERED, 1024>(h, p, x, y, blk_lo, col16, s);
+    else launch_bundle_block<MODE, ORDERED, 512>(h, p, x, y, blk_lo, col16, s);
 }
 
 // The plan of SPMV_WAVE_PIPE, a function of row_ptr and col_idx (not of the values): the rows of more than kBundleCap
@@ -720,12 +766,24 @@ int plan_wave(spmv_csr &h, hipStream_t s)
     p.d_piece_len = ln.release();
     p.d_partial = part.release();
     // the windows: the bundle kernel in its plan mode (the same runs and pieces, minimum and maximum column instead of products)
-    launch_bundle<2>(h, p, nullptr, nullptr, blk_lo.p, s);
+    launch_bundle<2>(h, p, nullptr, nullptr, blk_lo.p, nullptr, s);
     if (int rc = check_launch("k_wave_bundle<plan>")) return rc;
     std::vector<int32_t> wl((size_t)p.blocks);
     SPMV_HIP_TRY(hipMemcpyAsync(wl.data(), blk_lo.p, sizeof(int32_t) * (size_t)p.blocks, hipMemcpyDeviceToHost, s));
     SPMV_HIP_TRY(hipStreamSynchronize(s));      // (also: bl / bp are host memory of this call)
     for (int64_t i = 0; i < p.blocks; ++i) p.win_blocks += wl[(size_t)i] >= 0;
+    const char *c16env = getenv("SPMV_WAVE_COL16");
+    if (2 * p.win_blocks >= p.blocks && !(c16env && c16env[0] == '0')) {
+        // the 16-bit offsets into the windows (2 bytes per nonzero of device memory; the blocks without a window and the
+        // long rows leave their entries unwritten and unread)
+        DevPtr<uint16_t> c16;
+        SPMV_HIP_TRY(c16.alloc((size_t)h.nnz));
+        launch_bundle<3>(h, p, nullptr, nullptr, blk_lo.p, c16.p, s);
+        if (int rc = check_launch("k_wave_bundle<col16>")) return rc;
+        SPMV_HIP_TRY(hipStreamSynchronize(s));
+        p.d_col16 = c16.release();
+    }
+    p.windows = 2 * p.win_blocks >= p.blocks;
     p.d_blk_lo = blk_lo.release();
     p.ready = true;
     return SPMV_OK;
@@ -748,8 +806,8 @@ int launch_scalar(spmv_csr &h, const float *x, float *y, hipStream_t s)
         // windows that variant's plan provides (made here on the first run of a handle that was not planned)
         if (int rc = plan_wave(h, s)) return rc;
         const WavePlan &p = h.plan_wave;
-        if (2 * p.win_blocks >= p.blocks) launch_bundle<1, true>(h, p, x, y, p.d_blk_lo, s);
-        else launch_bundle<0, true>(h, p, x, y, nullptr, s);
+        if (p.windows) launch_bundle<1, true>(h, p, x, y, p.d_blk_lo, p.d_col16, s);
+        else launch_bundle<0, true>(h, p, x, y, nullptr, nullptr, s);
         return check_launch("k_wave_bundle<ordered>");
     }
     hipLaunchKernelGGL(k_scalar, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr,
@@ -774,8 +832,8 @@ int launch_wave(spmv_csr &h, const float *x, float *y, bool pipelined, hipStream
         const WavePlan &p = h.plan_wave;
         // windows where at least half of the blocks have one (their 35 KiB leave two workgroups per CU); else every
         // gather goes to memory, from three workgroups per CU
-        if (2 * p.win_blocks >= p.blocks) launch_bundle<1>(h, p, x, y, p.d_blk_lo, s);
-        else launch_bundle<0>(h, p, x, y, nullptr, s);
+        if (p.windows) launch_bundle<1>(h, p, x, y, p.d_blk_lo, p.d_col16, s);
+        else launch_bundle<0>(h, p, x, y, nullptr, nullptr, s);
 #ifndef SPMV_R_NOLONG
         if (p.n_long) {
             if (int rc = check_launch("k_wave_bundle")) return rc;
