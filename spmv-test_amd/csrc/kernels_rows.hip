@@ -538,9 +538,13 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
 
 // one wavefront per piece of kPieceLen nonzeros, wherever on the chip there is room: partial[p] = sum of its products (x from
 // memory: the long rows' columns are the wide ones; no LDS, eight waves per SIMD, 2 x 16 loads in flight each)
+// piece_base[p] >= 0: the piece's columns are read as the plan's 16-bit offsets from that column (col16; 6 bytes per
+// nonzero), which the plan stores where a piece spans fewer than 65 536 columns.
 template <bool BUFX>
 __global__ __launch_bounds__(kBlock) void k_wave_pieces(int npieces, uint32_t x_bytes, const int32_t *__restrict__ piece_k0,
                                                         const int32_t *__restrict__ piece_len,
+                                                        const int32_t *__restrict__ piece_base,
+                                                        const uint16_t *__restrict__ col16,
                                                         const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
                                                         const float *__restrict__ x, float *__restrict__ partial)
 {
@@ -550,9 +554,16 @@ __global__ __launch_bounds__(kBlock) void k_wave_pieces(int npieces, uint32_t x_
     if (p >= npieces) return;   // wave-uniform
     const __amdgpu_buffer_rsrc_t xr = rsrc_of(x, x_bytes);
     const int32_t k0 = __builtin_amdgcn_readfirstlane(piece_k0[p]), len = __builtin_amdgcn_readfirstlane(piece_len[p]);
+    const int32_t base = piece_base ? __builtin_amdgcn_readfirstlane(piece_base[p]) : -1;
     int32_t c[S];
     float v[S];
-    bundle_loads<S>(lane, k0, len, col_idx, vals, c, v);
+    if (base >= 0) {
+        bundle_loads16<S>(lane, k0, len, col16, vals, c, v);
+#pragma unroll
+        for (int u = 0; u < S; ++u) c[u] += base;
+    } else {
+        bundle_loads<S>(lane, k0, len, col_idx, vals, c, v);
+    }
     bundle_multiply<BUFX, S>(lane, len, xr, x, nullptr, 0, 0u, c, v);
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
@@ -566,6 +577,34 @@ __global__ __launch_bounds__(kBlock) void k_wave_pieces(int npieces, uint32_t x_
     }
     const float acc = wave_reduce_sum((a0 + a1) + (a2 + a3));
     if (lane == 0) partial[p] = acc;
+}
+
+// plan pass: one wavefront per piece -- its smallest column is its base; where the piece spans fewer than 65 536 columns the
+// offsets from the base go to col16 (the entries of a long row's nonzeros, which the bundle pass leaves alone)
+__global__ __launch_bounds__(kBlock) void k_wave_plan_piece16(int npieces, const int32_t *__restrict__ piece_k0,
+                                                              const int32_t *__restrict__ piece_len,
+                                                              const int32_t *__restrict__ col_idx, int32_t *__restrict__ piece_base,
+                                                              uint16_t *__restrict__ col16)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int p = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (p >= npieces) return;
+    const int32_t k0 = piece_k0[p], len = piece_len[p];
+    int32_t cmin = 0x7fffffff, cmax = -1;
+    for (int32_t k = lane; k < len; k += kWave) {
+        const int32_t c = col_idx[k0 + k];
+        cmin = min(cmin, c);
+        cmax = max(cmax, c);
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        cmin = min(cmin, __shfl_xor(cmin, o));
+        cmax = max(cmax, __shfl_xor(cmax, o));
+    }
+    const bool fits = cmax - cmin < 65536;
+    if (lane == 0) piece_base[p] = fits ? cmin : -1;
+    if (fits)
+        for (int32_t k = lane; k < len; k += kWave) col16[k0 + k] = (uint16_t)(col_idx[k0 + k] - cmin);
 }
 
 // one thread per long row: its pieces added in order
@@ -686,6 +725,7 @@ void destroy_wave(WavePlan &p)
     (void)hipFree(p.d_partial);
     (void)hipFree(p.d_blk_lo);
     (void)hipFree(p.d_col16);
+    (void)hipFree(p.d_piece_base);
     p = WavePlan{};
 }
 
@@ -773,17 +813,28 @@ int plan_wave(spmv_csr &h, hipStream_t s)
     SPMV_HIP_TRY(hipStreamSynchronize(s));      // (also: bl / bp are host memory of this call)
     for (int64_t i = 0; i < p.blocks; ++i) p.win_blocks += wl[(size_t)i] >= 0;
     const char *c16env = getenv("SPMV_WAVE_COL16");
-    if (2 * p.win_blocks >= p.blocks && !(c16env && c16env[0] == '0')) {
-        // the 16-bit offsets into the windows (2 bytes per nonzero of device memory; the blocks without a window and the
-        // long rows leave their entries unwritten and unread)
+    p.windows = 2 * p.win_blocks >= p.blocks;
+    if ((p.windows || np) && !(c16env && c16env[0] == '0')) {
+        // 16-bit column offsets, 2 bytes per nonzero of device memory: into the block's window for the short rows of a block
+        // that has one, from the piece's smallest column for the pieces of the long rows (where a piece spans fewer than
+        // 65 536 columns); what neither covers stays unwritten and unread
         DevPtr<uint16_t> c16;
+        DevPtr<int32_t> pbase;
         SPMV_HIP_TRY(c16.alloc((size_t)h.nnz));
-        launch_bundle<3>(h, p, nullptr, nullptr, blk_lo.p, c16.p, s);
-        if (int rc = check_launch("k_wave_bundle<col16>")) return rc;
+        if (p.windows) {
+            launch_bundle<3>(h, p, nullptr, nullptr, blk_lo.p, c16.p, s);
+            if (int rc = check_launch("k_wave_bundle<col16>")) return rc;
+        }
+        if (np) {
+            SPMV_HIP_TRY(pbase.alloc((size_t)np));
+            hipLaunchKernelGGL(k_wave_plan_piece16, dim3((unsigned)((np + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, s,
+                               (int)np, p.d_piece_k0, p.d_piece_len, h.d_col_idx, pbase.p, c16.p);
+            if (int rc = check_launch("k_wave_plan_piece16")) return rc;
+        }
         SPMV_HIP_TRY(hipStreamSynchronize(s));
         p.d_col16 = c16.release();
+        p.d_piece_base = pbase.release();
     }
-    p.windows = 2 * p.win_blocks >= p.blocks;
     p.d_blk_lo = blk_lo.release();
     p.ready = true;
     return SPMV_OK;
@@ -840,10 +891,10 @@ int launch_wave(spmv_csr &h, const float *x, float *y, bool pipelined, hipStream
             const dim3 pgrid((unsigned)((p.pieces + kRowsPerBlock - 1) / kRowsPerBlock));
             if (h.cols < (1LL << 30))
                 hipLaunchKernelGGL(k_wave_pieces<true>, pgrid, dim3(kBlock), 0, s, p.pieces, (uint32_t)(h.cols * 4), p.d_piece_k0,
-                                   p.d_piece_len, h.d_col_idx, h.d_vals, x, p.d_partial);
+                                   p.d_piece_len, p.d_piece_base, p.d_col16, h.d_col_idx, h.d_vals, x, p.d_partial);
             else
                 hipLaunchKernelGGL(k_wave_pieces<false>, pgrid, dim3(kBlock), 0, s, p.pieces, 0u, p.d_piece_k0, p.d_piece_len,
-                                   h.d_col_idx, h.d_vals, x, p.d_partial);
+                                   p.d_piece_base, p.d_col16, h.d_col_idx, h.d_vals, x, p.d_partial);
             if (int rc = check_launch("k_wave_pieces")) return rc;
             hipLaunchKernelGGL(k_wave_combine, dim3((unsigned)((p.n_long + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, p.n_long,
                                p.d_long_row, p.d_long_first, p.d_partial, y);

@@ -150,7 +150,8 @@ struct WavePlan {
     float *d_partial = nullptr;       // [pieces] scratch of a run: the pieces' sums
     int block_rows = 512;             // rows of a bundle workgroup (512 | 1024)
     int32_t *d_blk_lo = nullptr;      // [blocks] first entry of the x window of every block of block_rows rows, -1: none
-    uint16_t *d_col16 = nullptr;      // [nnz] column - blk_lo of the nonzeros of windowed blocks' short rows (null: not built)
+    uint16_t *d_col16 = nullptr;      // [nnz] 16-bit column offsets: from blk_lo for windowed blocks' short rows, from piece_base for pieces (null: not built)
+    int32_t *d_piece_base = nullptr;  // [pieces] smallest column of a piece whose offsets are in d_col16, -1: 32-bit columns
     bool windows = false;             // the bundle kernel stages windows (at least half of the blocks have one)
     int64_t blocks = 0, win_blocks = 0;   // blocks of block_rows rows, and how many have a window
 };
