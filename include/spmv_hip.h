@@ -150,7 +150,7 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
  * boundaries, column windows, for SPMV_TILED also a 16-bit copy of the column
  * indices; workgroup size and pass budget follow from the chunk statistics,
  * with SPMV_AUTOTUNE=1 from timed trial launches instead); a no-op for
- * SCALAR/WAVE.  A handle belongs to the device that was current when it was
+ * SPMV_WAVE; SPMV_SCALAR and SPMV_WAVE_PIPE share one (see the enum).  A handle belongs to the device that was current when it was
  * created: plan and run fail with SPMV_ERR_INVALID under another current device.  Excluded from the timed SpMV like the reference
  * excludes its host format build from TIME_KERNEL (e.g. wsp.cu:146 vs :167).
  * A plan snapshots the sparsity PATTERN (row_ptr, col_idx): with borrowed
@@ -162,7 +162,9 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
  * vals byte for byte in what a run reads, and is limited to 2^29 columns).
  * spmv_csr_run: enqueue y = A x on `stream` (a hipStream_t, NULL = default).
  * Asynchronous; d_x has cols floats, d_y has rows floats and is fully
- * overwritten.  No allocation, no synchronisation: graph-capturable. */
+ * overwritten.  No allocation, no synchronisation: graph-capturable -- with
+ * one exception: SPMV_SCALAR / SPMV_WAVE_PIPE on a handle that spmv_csr_plan
+ * has not seen make their plan on the first run (an allocation and a wait). */
 SPMV_API int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream);
 SPMV_API int spmv_csr_run(spmv_csr_t *h, int variant, const float *d_x, float *d_y, void *stream);
 

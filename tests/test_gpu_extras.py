@@ -20,7 +20,7 @@ def test_run_is_graph_capturable(pkg, oracle, gpu):
     w = pkg.workloads.config("c4", band=4096, scale=1 / 64)
     prob = synth_problem(pkg, oracle, gpu, w)
     y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
-    for name in ("adaptive", "tiled", "vector"):
+    for name in ("adaptive", "tiled", "vector", "wave_pipe", "scalar"):
         v = pkg.capi.VARIANTS[name]
         prob.A.plan(v)
         prob.A.run(v, prob.d_x, prob.d_y)            # warm (module load, attribute set) outside capture
