@@ -245,6 +245,17 @@ SPMV_API int spmv_dense_gemv_ws(int M, int N, const float *d_A, const float *d_x
 SPMV_API int spmv_dense_gemv_host(int M, int N, const float *A_host, const float *x_host, float *y_host,
                                   int mode, float *kernel_ms);
 
+/* ---- the reference's ASP layout (the uncompressed one of its activation-sparsity launcher) -----
+ * replaces: ASPMatrix (src/asp.cpp:3-14, src/include/asp.hpp) and the read pattern of asp_kernel_v0/1/2
+ * (src/kernels/asp.cu:6-211).  spmv_asp_retile: d_A[M][N] row-major -> d_asp (M*N floats), the same array bit for
+ * bit: 32 x 32 blocks, column panel by column panel (asp[(bn/32 * M + j) * 32 + c] = A[j*N + bn + c]); M and N
+ * multiples of 32 (tester.cpp:10-11).  spmv_asp_gemv_ws: y = A^T x from that layout, a row of a panel skipped
+ * when its x is zero (asp.cu:20-26); workspace as for spmv_dense_gemv_ws mode 3; asynchronous, no allocation.
+ * (asp_gemv_gpu of include/kernel.hpp runs dense mode 3 on the row-major matrix -- the same skip without the copy.) */
+SPMV_API int spmv_asp_retile(int M, int N, const float *d_A, float *d_asp, void *stream);
+SPMV_API int spmv_asp_gemv_ws(int M, int N, const float *d_asp, const float *d_x, float *d_y, void *d_workspace,
+                              int64_t workspace_bytes, void *stream);
+
 /* ---- the reference's tiled bitmap-CSR format (dense-ish matrices, density > 1/32) -----
  * replaces: TCSRMatrix (src/tcsr.cpp:5-38, src/include/tcsr.hpp:4-23) and csr_tiling_kernel
  * with its launcher (src/kernels/csr_tiling.cu:24-166).  Same arrays, bit for bit: blk_idx

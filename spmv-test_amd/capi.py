@@ -57,6 +57,8 @@ SIGNATURES = {
     "spmv_dense_gemv": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _vp]),
     "spmv_dense_gemv_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "spmv_dense_gemv_ws": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _vp, C.c_int64, _vp]),
+    "spmv_asp_retile": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _vp]),
+    "spmv_asp_gemv_ws": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _vp, C.c_int64, _vp]),
     "spmv_dense_gemv_host": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.POINTER(C.c_float)]),
     "spmv_tcsr_from_dense_host": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
     "spmv_tcsr_from_dense_device": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),
@@ -387,6 +389,18 @@ def dense_gemv(A, x, y, mode: int, stream=None, workspace=None) -> None:
 
 def dense_gemv_workspace_bytes(N: int, mode: int) -> int:
     return lib().spmv_dense_gemv_workspace_bytes(N, mode)
+
+
+def asp_retile(A, out, stream=None) -> None:
+    """The reference's ASPMatrix layout of the dense device matrix A[M][N] into ``out`` (M*N floats)."""
+    M, N = A.shape
+    check(lib().spmv_asp_retile(M, N, _ptr(A), _ptr(out), _stream_handle(stream)))
+
+
+def asp_gemv(M: int, N: int, asp, x, y, workspace, stream=None) -> None:
+    """y = A^T x from the ASP layout, rows with x == 0 skipped; ``workspace``: dense_gemv_workspace_bytes(N, 3) bytes."""
+    check(lib().spmv_asp_gemv_ws(M, N, _ptr(asp), _ptr(x), _ptr(y), _ptr(workspace),
+                                 workspace.numel() * workspace.element_size(), _stream_handle(stream)))
 
 
 def synth_fill(seed, row0, n_local, rows, cols, band, row_ptr, col_idx, vals, stream=None) -> None:

@@ -860,6 +860,30 @@ int spmv_dense_gemv_ws(int M, int N, const float *d_A, const float *d_x, float *
     return dense_gemv_ws(M, N, d_A, d_x, d_y, mode, d_workspace, (size_t)workspace_bytes, (hipStream_t)stream);
 }
 
+int spmv_asp_retile(int M, int N, const float *d_A, float *d_asp, void *stream)
+{
+    if (M < 0 || N < 0 || (M % 32) || (N % 32) || ((int64_t)M * N > 0 && (!d_A || !d_asp))) {
+        set_error("spmv_asp_retile: bad argument (M and N are multiples of 32, like the reference's tester asserts)");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return asp_retile(M, N, d_A, d_asp, (hipStream_t)stream);
+}
+
+int spmv_asp_gemv_ws(int M, int N, const float *d_asp, const float *d_x, float *d_y, void *d_workspace, int64_t workspace_bytes,
+                     void *stream)
+{
+    if (M < 0 || N < 0 || (M % 32) || (N % 32) || ((int64_t)M * N > 0 && (!d_asp || !d_x)) || (N > 0 && !d_y) ||
+        workspace_bytes < 0) {
+        set_error("spmv_asp_gemv_ws: bad argument");
+        return SPMV_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return asp_gemv_ws(M, N, d_asp, d_x, d_y, d_workspace, (size_t)workspace_bytes, (hipStream_t)stream);
+}
+
 int spmv_synth_fill(uint64_t seed, int64_t row0, int64_t n_local, int64_t rows, int64_t cols, int64_t band,
                     const int32_t *d_row_ptr, int32_t *d_col_idx, float *d_vals, void *stream)
 {

@@ -356,6 +356,78 @@ int dense_gemv_ws(int M, int N, const float *d_A, const float *d_x, float *d_y, 
     return SPMV_ERR_VARIANT;
 }
 
+// ---------------------------------------------------------------------------
+// The reference's ASP layout on the device (ASPMatrix, /root/reference/src/asp.cpp:3-14): A[M][N] re-tiled into 32 x 32
+// blocks, column panel by column panel -- which makes every panel of 32 columns one contiguous M x 32 row-major array:
+//   asp[(bn/32 * M + j) * 32 + c] = A[j * N + bn + c].
+// k_asp_retile copies A into it (128-byte reads and writes); k_asp_gemv multiplies from it with the x == 0 skip of
+// asp_kernel_v* (src/kernels/asp.cu:20-26) re-derived for 64 lanes: a wavefront owns one panel and takes TWO consecutive
+// rows per instruction (lanes 0-31 row j, lanes 32-63 row j + 1: 256 contiguous bytes), each half skipping its row when
+// its x is zero (a half that is masked off requests nothing); the halves meet through one shuffle at the end.  Rows split
+// into the same kSlabs slabs as modes 2/3, partials combined in slab order by k_gemv_combine.
+__global__ __launch_bounds__(kBlock) void k_asp_retile(int M, int N, const float *__restrict__ A, float *__restrict__ asp)
+{
+    const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int64_t panel = idx / ((int64_t)M * 32), rem = idx % ((int64_t)M * 32);
+    const int j = (int)(rem >> 5), c = (int)(rem & 31);
+    asp[idx] = A[(int64_t)j * N + panel * 32 + c];
+}
+
+__global__ __launch_bounds__(kBlock) void k_asp_gemv(int M, int N, const float *__restrict__ asp,
+                                                     const float *__restrict__ x, float *__restrict__ part)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int panel = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int s = blockIdx.y;
+    if (panel * 32 >= N) return;   // wave-uniform
+    int j0, j1;
+    slab_range(M, s, j0, j1);
+    const int half = lane >> 5, c = lane & 31;
+    const float *p = asp + (int64_t)panel * M * 32 + c;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int j = j0 + half;
+    for (; j + 6 < j1; j += 8) {       // four row pairs in flight
+        const float x0 = x[j], x1 = x[j + 2], x2 = x[j + 4], x3 = x[j + 6];
+        if (x0 != 0.0f) a0 = fmaf(x0, p[(int64_t)j * 32], a0);
+        if (x1 != 0.0f) a1 = fmaf(x1, p[(int64_t)(j + 2) * 32], a1);
+        if (x2 != 0.0f) a2 = fmaf(x2, p[(int64_t)(j + 4) * 32], a2);
+        if (x3 != 0.0f) a3 = fmaf(x3, p[(int64_t)(j + 6) * 32], a3);
+    }
+    for (; j < j1; j += 2) {
+        const float xj = x[j];
+        if (xj != 0.0f) a0 = fmaf(xj, p[(int64_t)j * 32], a0);
+    }
+    float acc = (a0 + a1) + (a2 + a3);
+    acc += __shfl_down(acc, 32, kWave);
+    if (half == 0) part[(size_t)s * N + panel * 32 + c] = acc;
+}
+
+int asp_retile(int M, int N, const float *d_A, float *d_asp, hipStream_t s)
+{
+    const int64_t n = (int64_t)M * N;
+    if (n == 0) return SPMV_OK;
+    hipLaunchKernelGGL(k_asp_retile, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, M, N, d_A, d_asp);
+    return check_launch("k_asp_retile");
+}
+
+int asp_gemv_ws(int M, int N, const float *d_asp, const float *d_x, float *d_y, void *d_ws, size_t ws_bytes, hipStream_t s)
+{
+    if (N == 0) return SPMV_OK;
+    if (!d_ws || ws_bytes < dense_gemv_workspace_bytes(N, 3)) {
+        set_error("spmv_asp_gemv_ws: needs %zu bytes of workspace, got %zu", dense_gemv_workspace_bytes(N, 3),
+                  d_ws ? ws_bytes : (size_t)0);
+        return SPMV_ERR_INVALID;
+    }
+    float *part = static_cast<float *>(d_ws);
+    const int panels = N / 32;
+    hipLaunchKernelGGL(k_asp_gemv, dim3((panels + kBlock / kWave - 1) / (kBlock / kWave), kSlabs), dim3(kBlock), 0, s, M, N,
+                       d_asp, d_x, part);
+    if (int rc = check_launch("k_asp_gemv")) return rc;
+    hipLaunchKernelGGL(k_gemv_combine, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, N, part, d_y);
+    return check_launch("k_gemv_combine");
+}
+
 // The library-owned workspace behind spmv_dense_gemv (the entry without a workspace argument): one buffer per
 // device, grown on demand, handed from call to call in STREAM ORDER -- a call on another stream than the last
 // user's first makes its stream wait for the event recorded behind that user's combine kernel.  So the entry is

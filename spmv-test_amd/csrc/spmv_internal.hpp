@@ -224,6 +224,9 @@ void drop_tiled_plan(spmv_csr &h);   // SPMV_AUTO resolved to another variant: t
 
 int dense_to_csr(int M, int N, const float *d_A, hipStream_t s, spmv_csr_t **out);
 int dense_gemv(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, hipStream_t s);
+// the reference's ASP layout (kernels_dense.hip): re-tile, and the multiply from it with the x == 0 skip
+int asp_retile(int M, int N, const float *d_A, float *d_asp, hipStream_t s);
+int asp_gemv_ws(int M, int N, const float *d_asp, const float *d_x, float *d_y, void *d_ws, size_t ws_bytes, hipStream_t s);
 size_t dense_gemv_workspace_bytes(int N, int mode);
 int dense_gemv_ws(int M, int N, const float *d_A, const float *d_x, float *d_y, int mode, void *d_ws, size_t ws_bytes,
                   hipStream_t s);

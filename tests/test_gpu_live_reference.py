@@ -108,3 +108,43 @@ def test_device_bitmap_builders_against_the_live_reference(pkg, gpu, fmt, kind, 
     assert np.array_equal(dbm, bm) and len(dva) == len(va)
     assert np.array_equal(dva.view(np.uint32), va.view(np.uint32))
     B.close()
+
+
+@needs_ref
+@pytest.mark.parametrize("M,N,zero", [(32, 32, 0.0), (2048, 96, 0.9), (96, 4096, 0.97), (1056, 160, 0.3), (4096, 4096, 0.5)])
+def test_device_asp_layout_against_the_live_reference(pkg, oracle, gpu, M, N, zero):
+    """spmv_asp_retile against ASPMatrix (asp.cpp:3-14), bit for bit; then spmv_asp_gemv_ws from that layout -- the
+    x == 0 skip of asp_kernel_v* (asp.cu:20-26) with the tester's 50 %-zero x -- against the CSR oracle of the same
+    matrix."""
+    import torch
+    from _util import assert_close_to_oracle
+    lib = _ref()
+    capi = pkg.capi
+    A = _random_dense(M, N, zero, M * 5 + N)
+    A[np.isnan(A)] = 0.5                                  # (keep the product comparable: no NaN in the values here)
+    nb, nv = ctypes.c_int(), ctypes.c_int()
+    stats = (ctypes.c_int * 4)()
+    h = lib.ref_fmt_build(3, M, N, A.ctypes.data, ctypes.byref(nb), ctypes.byref(nv), stats)
+    ref = np.empty(nv.value, np.float32)
+    lib.ref_fmt_copy(h, None, ref.ctypes.data)
+    lib.ref_fmt_free(h)
+    assert nv.value == M * N
+    dA = torch.from_numpy(A).to(gpu)
+    d_asp = torch.empty(M * N, dtype=torch.float32, device=gpu)
+    capi.asp_retile(dA, d_asp)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_asp.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # the multiply from the layout
+    rng = np.random.default_rng(M + N)
+    x = rng.uniform(-1, 1, size=M).astype(np.float32)
+    x[rng.random(M) < 0.5] = 0.0
+    dx = torch.from_numpy(x).to(gpu)
+    dy = torch.full((N,), float("nan"), device=gpu)
+    ws = torch.empty(capi.dense_gemv_workspace_bytes(N, 3), dtype=torch.uint8, device=gpu)
+    capi.asp_gemv(M, N, d_asp, dx, dy, ws)
+    torch.cuda.synchronize()
+    rp, ci, va = oracle.csr_from_dense(A)
+    y64, mag = oracle.spmv_f64(rp, ci, va, x)
+    assert_close_to_oracle(dy.cpu().numpy(), y64, mag, f"asp layout {M}x{N}")
+    with pytest.raises(capi.SpmvError):
+        capi.asp_retile(torch.zeros(33, 32, device=gpu), torch.zeros(33 * 32, device=gpu))
