@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/asp_time.py -- activation-sparsity skip (f-2) on the dense slot: mode 2 vs mode 3, 50 %-zero x."""
+"""tools/asp_time.py -- activation-sparsity skip (f-2) on the dense slot: mode 2 vs mode 3 on the row-major matrix, and (round 3)
+the multiply from the reference's ASP layout (spmv_asp_gemv_ws), with 0 / 50 / 90 %-zero x."""
 import json, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -25,4 +26,15 @@ for (M, N) in [(4096, 4096), (16384, 16384)]:
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 50
             rec[f"mode{mode}_ms"] = round(ms, 4); rec[f"mode{mode}_dense_GBs"] = round(M * N * 4 / ms / 1e6, 1)
+        if M % 32 == 0 and N % 32 == 0:
+            asp = torch.empty(M * N, device=dev)
+            capi.asp_retile(A, asp)
+            ws = torch.empty(capi.dense_gemv_workspace_bytes(N, 3), dtype=torch.uint8, device=dev)
+            for _ in range(5): capi.asp_gemv(M, N, asp, x, y, ws)
+            e0.record()
+            for _ in range(50): capi.asp_gemv(M, N, asp, x, y, ws)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 50
+            rec["asp_layout_ms"] = round(ms, 4); rec["asp_layout_dense_GBs"] = round(M * N * 4 / ms / 1e6, 1)
+            del asp
         print(json.dumps(rec), flush=True)
