@@ -522,6 +522,7 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
             if (panel.sorted_mode)   // unit bases, block tables, the rows of the tail units, the empty slots of the units in use
                 return panel.units * 4 + (int64_t)panel.nblocks * 20 + panel.tail_units * 512;
             return (int64_t)panel.nblocks * (panel.npanels + 1) * 4 + ((int64_t)panel.nblocks + 1) * 4;
+        case SPMV_SCALAR:    // (the same plan; the ordered kernel does not use the pieces)
         case SPMV_WAVE_PIPE: // the long rows' list, piece table read, partial sums written and re-read (col16 REPLACES 4 of col_idx's bytes with 2)
             return (int64_t)h->plan_wave.n_long * 8 + (int64_t)h->plan_wave.pieces * 16 + h->plan_wave.blocks * 8;
         default: return 0;
