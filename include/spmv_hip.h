@@ -301,6 +301,22 @@ SPMV_API int spmv_synth_fill(uint64_t seed, int64_t row0, int64_t n_local, int64
                     void *stream);
 SPMV_API int spmv_synth_x(uint64_t seed, int64_t j0, int64_t n, float *d_x, void *stream);
 
+/* ---- measurement aids: kernels of KNOWN traffic + a marker dispatch ------------------------------------------
+ * The metric of this path is rocprofv3's FETCH_SIZE / WRITE_SIZE over the kernel time (role of the reference's
+ * profile.sh:18-20, a profiler around the executable).  The counters are uncalibrated outside 16-byte streams on
+ * gfx950, so a profiled process launches these beside the SpMV kernels and corrects per access class
+ * (bench.py --traffic-child; tools/summarize_profile.py).  spmv_calib_stream reads exactly `bytes` (a multiple of 16,
+ * buffer 16-byte aligned) with 16-byte loads.  spmv_calib_gather reads n_lines DISTINCT 128-byte lines of a table of
+ * table_lines lines (a power of two; 128 bytes each), one lane per line, neighbouring lanes far apart; touch = 1: one
+ * word per line, 2: one word in each 64-byte half, 4: one word in each 32-byte sector.  spmv_calib_marker launches an
+ * empty kernel (spmv::k_marker) of `id` workgroups of 64 threads: a cut mark in a per-dispatch counter file.
+ * d_sink: one float the kernels never write in practice. */
+SPMV_API int spmv_calib_stream(const void *d_src, int64_t bytes, float *d_sink, void *stream);
+SPMV_API int spmv_calib_gather(const float *d_table, int64_t table_lines, int64_t n_lines, int touch, float *d_sink,
+                               void *stream);
+SPMV_API int spmv_calib_store(float *d_dst, int64_t bytes, int width, void *stream);
+SPMV_API int spmv_calib_marker(int id, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

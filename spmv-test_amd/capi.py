@@ -77,6 +77,10 @@ SIGNATURES = {
     "spmv_synth_fill": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                   _i32p, _i32p, _f32p, _vp]),
     "spmv_synth_x": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, _f32p, _vp]),
+    "spmv_calib_stream": (C.c_int, [_vp, C.c_int64, _f32p, _vp]),
+    "spmv_calib_gather": (C.c_int, [_f32p, C.c_int64, C.c_int64, C.c_int, _f32p, _vp]),
+    "spmv_calib_store": (C.c_int, [_f32p, C.c_int64, C.c_int, _vp]),
+    "spmv_calib_marker": (C.c_int, [C.c_int, _vp]),
 }
 
 
@@ -410,3 +414,20 @@ def synth_fill(seed, row0, n_local, rows, cols, band, row_ptr, col_idx, vals, st
 
 def synth_x(seed, j0, n, x, stream=None) -> None:
     check(lib().spmv_synth_x(seed, j0, n, _ptr(x), _stream_handle(stream)))
+
+
+# -- measurement aids (kernels of known traffic for calibrating rocprofv3's counters; include/spmv_hip.h) ----------
+def calib_stream(src, nbytes: int, sink, stream=None) -> None:
+    check(lib().spmv_calib_stream(_ptr(src), nbytes, _ptr(sink), _stream_handle(stream)))
+
+
+def calib_gather(table, table_lines: int, n_lines: int, touch: int, sink, stream=None) -> None:
+    check(lib().spmv_calib_gather(_ptr(table), table_lines, n_lines, touch, _ptr(sink), _stream_handle(stream)))
+
+
+def calib_store(dst, nbytes: int, width: int, stream=None) -> None:
+    check(lib().spmv_calib_store(_ptr(dst), nbytes, width, _stream_handle(stream)))
+
+
+def calib_marker(ident: int, stream=None) -> None:
+    check(lib().spmv_calib_marker(ident, _stream_handle(stream)))

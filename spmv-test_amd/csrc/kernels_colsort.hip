@@ -896,6 +896,8 @@ int plan_colsort(spmv_csr &h, PanelPlan &p, int want_rows, int want_waves, hipSt
     if (h.rows == 0) {
         p.sb_rows = want_rows ? want_rows : 4096;
         p.sb_waves = want_waves ? want_waves : 8;
+        p.stamp.gen = h.values_gen;     // nothing was copied, but the plan is as fresh as any other made now
+        p.stamp.have_sum = false;
         p.ready = true;
         return SPMV_OK;
     }

@@ -381,7 +381,9 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
     __shared__ __attribute__((aligned(16))) float win_lds[MODE == 1 ? kWindow : 4];
     __shared__ int32_t smin[kWaves], smax[kWaves];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    // (readfirstlane: the compiler must SEE that the wave index, and with it every run's bounds and descriptor base, is
+    // wave-uniform -- otherwise each buffer load of a run is wrapped in a waterfall loop over its descriptor)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *prod = prod_all[MODE >= 2 ? 0 : wave];
     const __amdgpu_buffer_rsrc_t xr = rsrc_of(x, x_bytes);
     const int blk = xcd_item((int)blockIdx.x, (int)gridDim.x);          // this workgroup's block of BLOCK rows
@@ -421,7 +423,12 @@ __global__ __launch_bounds__(BLOCK) void k_wave_bundle(int64_t rows, int64_t col
     };
     next_run(0);
     run_loads();
-    if (MODE == 1) __syncthreads();         // the window has landed
+    if (MODE == 1) {
+        // s_barrier does not drain the vector-memory counter and LDS-DMA writes LDS when its load returns: every wave
+        // waits for its own pieces of the window (vmcnt(0); expcnt / lgkmcnt left alone) before the barrier
+        if (win) __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();                    // the window has landed
+    }
     int32_t cmin = 0x7fffffff, cmax = -1;
     while (i0 < n) {
         if (MODE == 2) {

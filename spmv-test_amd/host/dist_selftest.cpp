@@ -3,7 +3,7 @@
 // matrix multiplied by a single handle.  Also the worked example of INTEGRATION.md for a C++ caller.
 //
 //   spmv_dist_selftest [--ranks N] [--rows-per-rank R] [--band B] [--unequal] [--variant tiled|adaptive|scalar|auto] [--steps K]
-//                      [--pipeline S] [--exchange allgather|p2p|peer] [--local] [--footprint]
+//                      [--pipeline S] [--exchange allgather|p2p|peer] [--local] [--footprint] [--no-verify]
 // N defaults to the number of visible GPUs.  Matrix: (N*R)^2, 16 nonzeros per row (config 2's law), generated on
 // the devices by spmv_synth_fill; with --unequal the blocks hold R-17, R+17, ... rows (the all-gather-v path).
 // --pipeline S (round 3): the pipelined step of spmv_dist.h -- every rank's R rows as S block-cyclic blocks, the exchange
@@ -11,6 +11,8 @@
 // peer, or peer stores (hipMemcpyPeerAsync, no RCCL).  --local: ranks without a communicator (spmv_dist_init_local), as
 // many as asked on the visible devices round-robin -- the whole pipeline with world > 1 on a ONE-GPU box (peer stores only).
 // --footprint: the optional footprint exchange -- every rank receives only the rows of y its own columns reference.
+// --no-verify (with --pipeline): timing only, no single-handle reference -- the whole matrix of 8 x 16Mi rows has 2^31
+// nonzeros, one more than a handle takes (bench.py --exchange all times the peer-store pipeline at that size).
 // Prints one JSON line; exit code 0 iff every rank's y is bit-identical to the single-handle result.
 #include <hip/hip_runtime.h>
 
@@ -48,13 +50,13 @@ struct Rank {
     spmv_dist_pipe_t *pipe = nullptr;
 };
 
-static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint);
+static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint, bool verify);
 
 int main(int argc, char **argv)
 {
     int ndev = spmv_device_count();
     int64_t per = 1 << 18, band = 4096;
-    bool unequal = false, local = false, footprint = false;
+    bool unequal = false, local = false, footprint = false, verify = true;
     int variant = SPMV_TILED, steps = 20, pipeline = 0, exchange = SPMV_DIST_ALLGATHER;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -66,6 +68,7 @@ int main(int argc, char **argv)
         else if (a == "--unequal") unequal = true;
         else if (a == "--local") local = true;
         else if (a == "--footprint") footprint = true;
+        else if (a == "--no-verify") verify = false;
         else if (a == "--pipeline") pipeline = atoi(next());
         else if (a == "--exchange") {
             std::string v = next();
@@ -81,7 +84,7 @@ int main(int argc, char **argv)
     }
     if (ndev < 1 || (!local && ndev > spmv_device_count())) { fprintf(stderr, "HIP error: %d ranks asked, %d devices visible\n", ndev, spmv_device_count()); return EXIT_FAILURE; }
     if (local && spmv_device_count() < 1) { fprintf(stderr, "HIP error: no device visible\n"); return EXIT_FAILURE; }
-    if (pipeline > 0) return run_pipeline(ndev, per, band, variant, steps, pipeline, exchange, local, footprint);
+    if (pipeline > 0) return run_pipeline(ndev, per, band, variant, steps, pipeline, exchange, local, footprint, verify);
     if (local) { fprintf(stderr, "--local needs --pipeline S --exchange peer\n"); return 2; }
     const uint64_t seed = 20251031;
     const int64_t rows = per * ndev, cols = rows;
@@ -219,7 +222,7 @@ int main(int argc, char **argv)
 
 
 // ---- the pipelined step: S block-cyclic blocks per rank, exchange of group s under the multiply of block s+1 ------------
-static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint)
+static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint, bool verify)
 {
     if (footprint && exchange == SPMV_DIST_ALLGATHER) { fprintf(stderr, "--footprint needs --exchange p2p or peer\n"); return 2; }
     if (S < 1 || per % S) { fprintf(stderr, "--rows-per-rank must be a multiple of --pipeline\n"); return 2; }
@@ -322,37 +325,39 @@ static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int st
     step(); step(); step();      // three in a row: the cross-step ordering (product s waits for the last exchange of group s)
     finish_all();
 
-    // the whole matrix through ONE handle on device 0, planned alike
+    // the whole matrix through ONE handle on device 0, planned alike (--no-verify: timing only)
     OK_HIP(hipSetDevice(rk[0].device));
     const int64_t nnz_all = rows * nnz_row;
-    std::vector<int32_t> rp_all(rows + 1);
-    for (int64_t i = 0; i <= rows; ++i) rp_all[i] = (int32_t)(i * nnz_row);
-    int32_t *d_rp, *d_ci;
-    float *d_va, *d_yref;
-    OK_HIP(hipMalloc((void **)&d_rp, sizeof(int32_t) * (rows + 1)));
-    OK_HIP(hipMalloc((void **)&d_ci, sizeof(int32_t) * nnz_all));
-    OK_HIP(hipMalloc((void **)&d_va, sizeof(float) * nnz_all));
-    OK_HIP(hipMalloc((void **)&d_yref, sizeof(float) * rows));
-    OK_HIP(hipMemcpy(d_rp, rp_all.data(), sizeof(int32_t) * (rows + 1), hipMemcpyHostToDevice));
-    OK_SPMV(spmv_synth_fill(seed, 0, rows, rows, cols, band, d_rp, d_ci, d_va, rk[0].stream));
     spmv_csr_t *whole = nullptr;
-    OK_SPMV(spmv_csr_create_device(rows, cols, nnz_all, d_rp, d_ci, d_va, &whole));
-    OK_SPMV(spmv_csr_plan_set(whole, variant, params, rk[0].stream));
-    OK_SPMV(spmv_csr_run(whole, variant, rk[0].d_x, d_yref, rk[0].stream));
-    OK_HIP(hipStreamSynchronize(rk[0].stream));
-    std::vector<float> yref(rows), y(rows);
-    OK_HIP(hipMemcpy(yref.data(), d_yref, sizeof(float) * rows, hipMemcpyDeviceToHost));
     int64_t differing = 0, untouched = 0;
-    for (int r = 0; r < ndev; ++r) {
-        OK_HIP(hipSetDevice(rk[r].device));
-        OK_HIP(hipMemcpy(y.data(), rk[r].d_y, sizeof(float) * rows, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < rows; ++i) {
-            // with a footprint a rank holds y on its own rows and inside its footprint; the rest keeps the NaN it was preset to
-            const bool own = (i / sub) % ndev == r;
-            bool needed = !footprint || own;
-            for (int s = 0; s < S && !needed; ++s) needed = i >= need_lo[(size_t)r * S + s] && i < need_hi[(size_t)r * S + s];
-            if (needed) differing += std::memcmp(&y[i], &yref[i], sizeof(float)) != 0;
-            else untouched += y[i] != y[i];
+    if (verify) {
+        std::vector<int32_t> rp_all(rows + 1);
+        for (int64_t i = 0; i <= rows; ++i) rp_all[i] = (int32_t)(i * nnz_row);
+        int32_t *d_rp, *d_ci;
+        float *d_va, *d_yref;
+        OK_HIP(hipMalloc((void **)&d_rp, sizeof(int32_t) * (rows + 1)));
+        OK_HIP(hipMalloc((void **)&d_ci, sizeof(int32_t) * nnz_all));
+        OK_HIP(hipMalloc((void **)&d_va, sizeof(float) * nnz_all));
+        OK_HIP(hipMalloc((void **)&d_yref, sizeof(float) * rows));
+        OK_HIP(hipMemcpy(d_rp, rp_all.data(), sizeof(int32_t) * (rows + 1), hipMemcpyHostToDevice));
+        OK_SPMV(spmv_synth_fill(seed, 0, rows, rows, cols, band, d_rp, d_ci, d_va, rk[0].stream));
+        OK_SPMV(spmv_csr_create_device(rows, cols, nnz_all, d_rp, d_ci, d_va, &whole));
+        OK_SPMV(spmv_csr_plan_set(whole, variant, params, rk[0].stream));
+        OK_SPMV(spmv_csr_run(whole, variant, rk[0].d_x, d_yref, rk[0].stream));
+        OK_HIP(hipStreamSynchronize(rk[0].stream));
+        std::vector<float> yref(rows), y(rows);
+        OK_HIP(hipMemcpy(yref.data(), d_yref, sizeof(float) * rows, hipMemcpyDeviceToHost));
+        for (int r = 0; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            OK_HIP(hipMemcpy(y.data(), rk[r].d_y, sizeof(float) * rows, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < rows; ++i) {
+                // with a footprint a rank holds y on its own rows and inside its footprint; the rest keeps the NaN it was preset to
+                const bool own = (i / sub) % ndev == r;
+                bool needed = !footprint || own;
+                for (int s = 0; s < S && !needed; ++s) needed = i >= need_lo[(size_t)r * S + s] && i < need_hi[(size_t)r * S + s];
+                if (needed) differing += std::memcmp(&y[i], &yref[i], sizeof(float)) != 0;
+                else untouched += y[i] != y[i];
+            }
         }
     }
 
@@ -393,17 +398,17 @@ static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int st
     const char *xname = exchange == SPMV_DIST_ALLGATHER ? "allgather" : exchange == SPMV_DIST_P2P ? "p2p" : "peer";
     printf("{\"world\": %d, \"process_model\": \"%s\", \"pipeline_blocks_per_rank\": %d, \"exchange\": \"%s\", \"rows\": %lld, "
            "\"nnz\": %lld, \"band\": %lld, \"variant\": \"%s\", \"footprint_exchange\": %s, \"rows_never_sent_to_a_rank_that_does_not_need_them\": %lld, "
-           "\"rows_differing_from_single_handle\": %lld, \"step_ms\": %.5f, "
+           "\"rows_differing_from_single_handle\": %lld, \"verified\": %s, \"step_ms\": %.5f, "
            "\"multiply_only_ms\": %.5f, \"exchange_only_ms\": %.5f, \"aggregate_GBs\": %.1f, \"plan\": \"%s\"}\n",
            ndev, local ? "one process, local ranks (no communicator), devices round-robin" : "one process, ncclCommInitAll", S, xname,
            (long long)rows, (long long)nnz_all, (long long)band, spmv_variant_name(variant), footprint ? "true" : "false",
-           (long long)untouched, (long long)differing, step_ms, mult_ms, xchg_ms, bytes / (step_ms * 1e-3) / 1e9, plan);
+           (long long)untouched, (long long)differing, verify ? "true" : "false", step_ms, mult_ms, xchg_ms, bytes / (step_ms * 1e-3) / 1e9, plan);
     for (int r = 0; r < ndev; ++r) {
         OK_HIP(hipSetDevice(rk[r].device));
         (void)spmv_dist_pipe_destroy(rk[r].pipe);
         for (int s = 0; s < S; ++s) (void)spmv_csr_destroy(rk[r].blocks[s]);
         (void)spmv_dist_destroy(dist[r]);
     }
-    (void)spmv_csr_destroy(whole);
+    if (whole) (void)spmv_csr_destroy(whole);
     return differing == 0 ? 0 : 1;
 }
