@@ -351,6 +351,21 @@ static int plan_auto(spmv_csr &h, hipStream_t s)
         }
     }
     if (little_staged && x_beyond_l2) {
+        // x beyond every L2 (each gather would be a 128-byte line from the fabric) and tiles that still hold a line or
+        // two of products: the binned layout -- two streaming launches, nothing gathered from memory
+        // (measured, profiles/r04_binned_*.jsonl: config 4 uniform 1.33 -> 1.06 ms at 83 nonzeros per tile, config 3 uniform
+        // 0.86 -> 0.52 ms at 663; config 5's shard 3.0 -> 4.1 ms at 10: below ~48 the sum launch works on quarter-empty pieces)
+        bool try_binned = h.cols * (int64_t)sizeof(float) >= (8ll << 20) && binned_tile_nonzeros(h, 4096) >= 48.0;
+        if (const char *e = getenv("SPMV_AUTO_BINNED")) try_binned = try_binned && atoi(e) != 0;   // 0: never (A/B runs)
+        if (try_binned) {
+            rc = build_panel(h, h.plan_auto_panel, 0, 0, 4, s);
+            if (rc == SPMV_OK) {
+                h.auto_variant = SPMV_PANEL;
+                release_tiled();
+                return SPMV_OK;
+            }
+            if (rc != SPMV_ERR_INVALID) return rc;   // INVALID: outside the layout's limits -> the sweep
+        }
         rc = build_panel(h, h.plan_auto_panel, 0, 0, 1, s);
         if (rc == SPMV_OK) {
             h.auto_variant = SPMV_PANEL;
@@ -451,8 +466,9 @@ int spmv_csr_plan_get(const spmv_csr_t *h, int variant, int32_t params[8])
         case SPMV_PANEL:
             if (!panel.ready) { set_error("spmv_csr_plan_get: panel is not planned"); return SPMV_ERR_NOT_PLANNED; }
             params[4] = panel.pw_bits; params[5] = panel.waves_per_launch;
-            params[6] = panel.sorted_mode ? 3 : (panel.lds_mode ? 2 : 1);
+            params[6] = panel.binned_mode ? 4 : panel.sorted_mode ? 3 : (panel.lds_mode ? 2 : 1);
             if (panel.sorted_mode) { params[4] = panel.sb_rows; params[5] = panel.sb_waves; }
+            if (panel.binned_mode) { params[4] = panel.bin_rows; params[5] = 0; }
             return SPMV_OK;
         default: set_error("spmv_csr_plan_get: unknown variant %d", variant); return SPMV_ERR_VARIANT;
     }
@@ -519,6 +535,8 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
             return (int64_t)h->plan_xskip.nseg * 8 + ((int64_t)h->plan_xskip.nblocks + 1) * 4 +
                    (h->plan_xskip.slabs > 1 ? (int64_t)h->plan_xskip.nblocks * h->plan_xskip.slabs * 1024 * 8 : 0);
         case SPMV_PANEL:     // tile_ptr; packed/pvals REPLACE col_idx/vals byte for byte (sorted blocks: + the empty slots)
+            if (panel.binned_mode)   // two tables per tile, 16-bit columns and rows, the products written and read back; pvals REPLACES vals
+                return (int64_t)panel.nblocks * (2 * (int64_t)panel.npanels + 2) * 4 + panel.padded * (2 + 4 + 4) + h->nnz * 2;
             if (panel.sorted_mode)   // unit bases, block tables, the rows of the tail units, the empty slots of the units in use
                 return panel.units * 4 + (int64_t)panel.nblocks * 20 + panel.tail_units * 512;
             return (int64_t)panel.nblocks * (panel.npanels + 1) * 4 + ((int64_t)panel.nblocks + 1) * 4;
@@ -551,6 +569,11 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
                       h->plan_wave.pieces, h->plan_wave.block_rows, (long long)h->plan_wave.blocks, (long long)h->plan_wave.win_blocks,
                       h->plan_wave.d_col16 ? 1 : 0);
     }
+    else if (variant == SPMV_PANEL && panel->ready && panel->binned_mode)
+        snprintf(buf, (size_t)n, "binned bins=%d rows_per_bin=%d panels=%d panel_columns=%d nonzeros_per_tile=%.1f products_per_lane=%d long_rows=%d flagged_tiles=%d product_workgroups_per_panel=%d padded=%lld",
+                 panel->nblocks, panel->bin_rows, panel->npanels, 1 << panel->pw_bits,
+                 panel->nblocks ? (double)h->nnz / ((double)panel->nblocks * panel->npanels) : 0.0, panel->wide_pieces ? 4 : 2, panel->long_rows, panel->flagged_tiles, panel->splits,
+                 (long long)panel->padded);
     else if (variant == SPMV_PANEL && panel->ready && panel->sorted_mode)
         snprintf(buf, (size_t)n, "sorted_blocks=%d rows_per_block=%d wavefronts=%d lines_per_nonzero=%.3f tail_nonzeros=%lld wide_blocks=%lld model_cost=%.3f",
                  panel->nblocks, panel->sb_rows, panel->sb_waves,

@@ -1,0 +1,635 @@
+// kernels_binned.hip -- SPMV_PANEL mode 4, "binned": y = A x for columns WITHOUT locality as two pure streams.
+//
+// Why.  The reference's only structure law is i.i.d. uniform positions
+// (/root/reference/src/tester.cpp:103-121).  On such a matrix every gather design of this library pays one L2 line
+// request per nonzero: the panel sweep (kernels_panel.hip) moves 1.4 x the algorithmic bytes at config 4 and 7.9 x at
+// config 5's shard, bound by the 270 G line requests per second the L2s serve.  Here NOTHING is gathered from memory:
+//
+//   launch 1  k_bin_products   the nonzeros in PANEL-major order (16-bit column inside the panel + value: 6 B); a
+//             workgroup stages its panel of x (2^15 columns, 128 KiB) in LDS by LDS-DMA, streams its share of the
+//             panel's nonzeros with 16-byte loads and writes the products x[col] * val, 16 bytes per lane, in the same
+//             order (4 B per nonzero).
+//   launch 2  k_bin_sums       the rows in BINS of at most 8192 (4096); a wavefront owns a bin, its sums private in LDS.
+//             Tile (bin b, panel p) is contiguous in the panel-major product array; the wavefront walks its bin's
+//             tiles, 64 products and their 16-bit rows (2 B, bin-major: contiguous for the whole bin) per instruction,
+//             eight instructions' loads in flight, and adds with a plain LDS read-add-write: rows ascend inside a
+//             tile, so equal rows are neighbouring lanes -- folded in registers first (a shift and a compare find
+//             them; pairs directly, longer runs by a segmented scan).  No atomics, no barrier, deterministic.
+//
+// 6 + 4 + 4 + 2 = 16 bytes per nonzero of perfectly sequential traffic, x and y once, 8 bytes of tables per tile
+// -- against 8 B per nonzero plus a 128-byte line per gather.  The plan (device side, once): bins = row blocks of equal
+// NONZERO counts (panel_row_blocks), a histogram of tiles, two prefix orders, one stable scatter.  The values are
+// COPIED (like every layout of the panel family): spmv_csr_values_changed -> re-plan.
+//
+// Role: the sparse-scale counterpart of the reference's tiled format -- TCSRMatrix (src/tcsr.cpp:5-38) multiplied by
+// csr_tiling_kernel (src/kernels/csr_tiling.cu:24-114): x tile in shared memory, tile values streamed.
+#include <climits>
+#include <cstdlib>
+#include "spmv_internal.hpp"
+
+namespace spmv {
+
+namespace {
+
+constexpr int kPwBits = 15;                // columns per panel: 128 KiB of x in LDS
+constexpr int kPw = 1 << kPwBits;
+constexpr int kProdThreads = 1024;         // one 16-wavefront workgroup per CU holds the panel
+constexpr int kMaxPanels = 4096;           // (panel_tile_ptr's histogram) -> at most 2^27 columns
+constexpr int kSumWaves = 4;               // wavefronts per workgroup of the sum launch
+constexpr int kSpare = 512;                // spare sums per bin for its long rows (see k_bin_runs)
+
+
+using u4 = unsigned __attribute__((ext_vector_type(4)));
+using f4 = float __attribute__((ext_vector_type(4)));
+
+int check(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, what, __FILE__, __LINE__);
+    return SPMV_OK;
+}
+
+// ---- plan kernels ------------------------------------------------------------------------------------------------
+// nonzeros of every panel: total[p] = sum over bins of the tile counts, rounded up to a multiple of 8 (16-byte loads)
+__global__ __launch_bounds__(256) void k_bin_panel_totals(int nb, int np, const int32_t *__restrict__ tile_ptr, int32_t *__restrict__ total)
+{
+    __shared__ int part[256];
+    const int p = blockIdx.x;
+    int sum = 0;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+        sum += tp[p + 1] - tp[p];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[p] = (part[0] + 7) & ~7;
+}
+// pm[b * np + p] = pbase[p] + (nonzeros of panel p in the bins before b): one workgroup per panel scans the bins
+__global__ __launch_bounds__(256) void k_bin_pm(int nb, int np, const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ pbase,
+                                                int32_t *__restrict__ pm)
+{
+    __shared__ int part[256];
+    __shared__ int carry;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) carry = pbase[p];
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int b = b0 + tid;
+        int c = 0;
+        if (b < nb) {
+            const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+            c = tp[p + 1] - tp[p];
+        }
+        part[tid] = c;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (b < nb) pm[(int64_t)b * np + p] = carry + part[tid] - c;
+        __syncthreads();
+        if (tid == 255) carry += part[255];
+        __syncthreads();
+    }
+}
+// Stable scatter of one bin into both orders: a wave per bin, 64 nonzeros per step in CSR order; the rank of a nonzero
+// among the same-panel nonzeros of its step comes from a ballot per distinct panel (the method of k_panel_fill).
+__global__ __launch_bounds__(256) void k_bin_fill(int nb, int np, const int32_t *__restrict__ brow, const int32_t *__restrict__ row_ptr,
+                                                  const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
+                                                  const uint16_t *__restrict__ rowloc, const int32_t *__restrict__ tile_ptr,
+                                                  const int32_t *__restrict__ pm, uint16_t *__restrict__ c16, float *__restrict__ pvals,
+                                                  uint16_t *__restrict__ r16)
+{
+    __shared__ int cursor_all[4][kMaxPanels];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= nb) return;
+    int *cursor = cursor_all[w];
+    const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+    const int32_t *qp = pm + (int64_t)b * np;
+    for (int p = lane; p < np; p += kWave) cursor[p] = tp[p];
+    const int s = row_ptr[brow[b]], e = row_ptr[brow[b + 1]];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = s; base < e; base += kWave) {
+        const int k = base + lane;
+        const bool valid = k < e;
+        int col = 0, rl = 0;
+        float v = 0.0f;
+        if (valid) {
+            col = col_idx[k];
+            rl = rowloc[k];
+            v = vals[k];
+        }
+        const int p = col >> kPwBits;
+        int dest = 0;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int pl = __shfl(p, leader);
+            const unsigned long long m = __ballot(valid && p == pl);
+            const int first = cursor[pl];
+            if (valid && p == pl) dest = first + __popcll(m & lt);
+            if (lane == leader) cursor[pl] = first + __popcll(m);
+            todo &= ~m;
+        }
+        if (valid) {
+            r16[dest] = (uint16_t)rl;                         // bin-major
+            const int q = qp[p] + (dest - tp[p]);             // the same rank inside the tile, panel-major
+            c16[q] = (uint16_t)(col & (kPw - 1));
+            pvals[q] = v;
+        }
+    }
+}
+
+// ---- launch 1: products in panel order ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kProdThreads) void k_bin_products(int splits, int64_t cols, const int32_t *__restrict__ pbase,
+                                                               const uint16_t *__restrict__ c16, const float *__restrict__ pvals,
+                                                               const float *__restrict__ x, float *__restrict__ prod)
+{
+    extern __shared__ __attribute__((aligned(16))) float xp[];      // the panel: kPw floats
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x / splits, part = blockIdx.x - p * splits;
+    const int64_t g0 = (int64_t)p << kPwBits;
+    if (g0 + kPw + 3 < cols) {                                      // workgroup-uniform
+#pragma unroll
+        for (int i = tid * 4; i < kPw; i += kProdThreads * 4) __builtin_amdgcn_global_load_lds(x + g0 + i, xp + i, 16, 0, 0);
+    } else {
+        for (int i = tid; i < kPw; i += kProdThreads) xp[i] = g0 + i < cols ? x[g0 + i] : 0.0f;
+    }
+    const int a0 = pbase[p], b0 = pbase[p + 1];                     // multiples of 8
+    const int units = (b0 - a0) >> 3, per = (units + splits - 1) / splits;
+    const int a = a0 + part * per * 8;
+    int b = a + per * 8;
+    if (b > b0) b = b0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): this wave's pieces of the panel have landed
+    __syncthreads();
+    for (int k = a + tid * 8; k < b; k += kProdThreads * 8) {
+        const u4 c = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(c16 + k));
+        const f4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(pvals + k));
+        const f4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(pvals + k + 4));
+        f4 o0, o1;
+        o0.x = xp[c.x & 0xffffu] * v0.x;
+        o0.y = xp[c.x >> 16] * v0.y;
+        o0.z = xp[c.y & 0xffffu] * v0.z;
+        o0.w = xp[c.y >> 16] * v0.w;
+        o1.x = xp[c.z & 0xffffu] * v1.x;
+        o1.y = xp[c.z >> 16] * v1.y;
+        o1.z = xp[c.w & 0xffffu] * v1.z;
+        o1.w = xp[c.w >> 16] * v1.w;
+        *reinterpret_cast<f4 *>(prod + k) = o0;
+        *reinterpret_cast<f4 *>(prod + k + 4) = o1;
+    }
+}
+
+// ---- launch 2: sums per bin -----------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// lane l receives lane l-1's value (lane 0: `first`): DPP wave_shr:1, one VALU instruction instead of a trip through the LDS crossbar
+__device__ __forceinline__ int shift_up1(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false); }
+
+// The general fold (flagged tiles only): 64 (cnt) products of one tile, one per lane, rows ascending; equal rows are
+// neighbouring lanes; their products are folded into the LAST lane of the run by a segmented scan, `row` becomes -1 on the
+// lanes that have nothing to add any more.
+__device__ __forceinline__ void fold_piece(int lane, int cnt, int &row, float &v)
+{
+    const bool valid = lane < cnt;
+    if (!valid) row = -1 - lane;                                    // never equal to a neighbour
+    const int prow = shift_up1(row, -2);
+    const bool dup = valid && prow == row;
+    const unsigned long long dm = __ballot(dup);
+    if (dm != 0ull) {
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {                       // rows ascend: equal at distance d = one run
+            const float tv = __shfl_up(v, d);
+            const int tr = __shfl_up(row, d);
+            if (lane >= d && tr == row) v += tv;
+        }
+        if (lane < kWave - 1 && ((dm >> (lane + 1)) & 1ull)) row = -1;   // not the last of its run
+    }
+    if (!valid) row = -1;
+}
+
+// A piece = up to 64 E consecutive products of ONE tile, E consecutive per lane (E = 4: a 16-byte load of products per
+// lane; E = 2 for thin tiles).  The lane adds its E products into the sums one after the other, entry k of every lane in
+// step k: rows ascend along the piece, so two products of one row are either in one lane (different steps) or in
+// neighbouring lanes at its last and first entry (different steps again) -- as long as no row holds more than E products
+// of the tile, no step ever holds a row twice, and the add is a plain LDS read-add-write with NO fold logic at all.  The
+// plan flags the few tiles where a row does hold more (bit 31 of their pm entry): those go, 64 products at a time, one per
+// lane, through the segmented scan above.  Dead entries (past the tile's end) add into a dummy word behind the sums.
+template <int RB, int E>
+__global__ __launch_bounds__(kSumWaves *kWave) void k_bin_sums(int nb, int np, const int32_t *__restrict__ brow,
+                                                               const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ pm,
+                                                               const uint16_t *__restrict__ r16, const float *__restrict__ prod,
+                                                               const int32_t *__restrict__ lptr, const uint32_t *__restrict__ lrow,
+                                                               const int32_t *__restrict__ lcnt, float *__restrict__ y)
+{
+    constexpr int kPiece = kWave * E, kShift = E == 4 ? 8 : 7, kD = E == 4 ? 4 : 8;   // pieces per register set
+    constexpr int kStride = RB + kSpare + kWave;                    // a wave's sums, the spare sums of its long rows, the dummy word
+    constexpr int kDummy = RB + kSpare;
+    extern __shared__ float sums_all[];                             // kSumWaves x kStride
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * kSumWaves + wave;
+    if (b >= nb) return;                                            // (no barrier below: a wave's sums are its own)
+    float *sums = sums_all + wave * kStride;
+    const int row0 = brow[b], nrows = brow[b + 1] - row0;
+    for (int i = lane; i < kDummy; i += kWave) sums[i] = 0.0f;
+    const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+    const int32_t *qp = pm + (int64_t)b * np;
+    typedef float fEu __attribute__((ext_vector_type(E), aligned(4)));
+    struct Set { fEu v[kD]; int r[kD][E]; int left[kD]; int q[kD], s[kD]; };
+    for (int tb = 0; tb < np; tb += kWave) {                        // 64 tiles of the bin: a lane holds one tile's three numbers
+        const int t = tb + lane;
+        int s_l = 0, n_l = 0, q_l = 0;
+        if (t < np) {
+            s_l = tp[t];
+            n_l = tp[t + 1] - s_l;
+            q_l = qp[t];
+        }
+        const int c_l = (n_l + kPiece - 1) >> kShift;               // pieces of this tile
+        const int pre = wave_inclusive_scan(c_l, lane);
+        const int total = __builtin_amdgcn_readlane(pre, kWave - 1);
+        const int excl = pre - c_l;
+        // the three table numbers are in registers before the first piece is addressed: the waits further down then count
+        // piece loads only (a wait for a table load issued on another control path would drain every piece in flight)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        // the loads of kD pieces, starting at piece ci0 of this batch of tiles.  No branch: a piece past the end loads a valid
+        // address and counts for nothing (left = 0); lanes past a tile's end read on into the next tile (the arrays have
+        // the slack) and add into the dummy word -- every path issues the same loads, the compiler's wait counters stay exact
+        // and one register set really is in flight under the other
+        auto issue = [&](int ci0, Set &c) {
+#pragma unroll
+            for (int u = 0; u < kD; ++u) {
+                const int ci = ci0 + u;
+                const bool live = ci < total;
+                int tl = __popcll(__ballot(pre <= ci));             // the tile this piece belongs to: first lane with pre > ci
+                tl = tl > kWave - 1 ? kWave - 1 : tl;
+                const int s = __builtin_amdgcn_readlane(s_l, tl), n = __builtin_amdgcn_readlane(n_l, tl);
+                const int q = __builtin_amdgcn_readlane(q_l, tl), ex = __builtin_amdgcn_readlane(excl, tl);
+                const int off = live ? (ci - ex) << kShift : 0;
+                c.left[u] = live ? n - off : 0;
+                c.q[u] = q + off;                                   // (bit 31 of q: the tile is flagged)
+                c.s[u] = s + off;
+                const int at = off + E * lane;
+                c.v[u] = *reinterpret_cast<const fEu *>(prod + (q & 0x7fffffff) + at);
+                const uint16_t *rp = r16 + s + at;
+#pragma unroll
+                for (int k = 0; k < E; ++k) c.r[u][k] = rp[k];
+            }
+        };
+        auto consume = [&](Set &c) {
+#pragma unroll
+            for (int u = 0; u < kD; ++u) {
+                const int left = c.left[u];
+                if (c.q[u] < 0 && left > 0) {                       // flagged tile: one product per lane, folded (rare)
+                    const int q = c.q[u] & 0x7fffffff, s = c.s[u];
+                    const int m = left < kPiece ? left : kPiece;
+                    for (int o = 0; o < m; o += kWave) {
+                        const int cnt = m - o < kWave ? m - o : kWave;
+                        int row = lane < cnt ? (int)r16[s + o + lane] : 0;
+                        float v = lane < cnt ? prod[q + o + lane] : 0.0f;
+                        fold_piece(lane, cnt, row, v);
+                        if (row >= 0) sums[row] += v;
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int k = 0; k < E; ++k) {                       // step k: entry k of every lane; a row is there at most once
+                    const int a = E * lane + k < left ? c.r[u][k] : kDummy;
+                    sums[a] += c.v[u][k];
+                }
+            }
+        };
+        Set sa, sb;
+        issue(0, sa);
+        for (int ci0 = 0; ci0 < total; ci0 += 2 * kD) {             // two register sets: one in flight while the other is summed
+            issue(ci0 + kD, sb);
+            consume(sa);
+            issue(ci0 + 2 * kD, sa);
+            consume(sb);
+        }
+    }
+    // the long rows of the bin: their spare sums join the row's own, in slot order
+    for (int i = lptr[b] + lane; i < lptr[b + 1]; i += kWave) {
+        const uint32_t w = lrow[i];
+        const int row = (int)(w >> 16), base = RB + (int)(w & 0xffffu), n = lcnt[i];
+        float t = sums[row];
+        for (int c = 0; c < n; ++c) t += sums[base + c];
+        sums[row] = t;
+    }
+    for (int i = lane; i < nrows; i += kWave) y[row0 + i] = sums[i];
+}
+
+// ---- plan: long rows --------------------------------------------------------------------------------------------------
+// A row that holds m > E products of some tile would meet itself in a step of the sum launch.  Its products number
+// E, E+1, ... of that tile go to SPARE sums instead (slot j / E - 1 of the row's spare sums: again E consecutive products per
+// slot, never two in one step), and the spare sums join the row's own at the end of the bin.
+// pass 1: maxrun[row] = the most products any tile holds of the row (where more than E); one thread per tile
+__global__ __launch_bounds__(256) void k_bin_runs(int np, int e, const int32_t *__restrict__ brow, const int32_t *__restrict__ tile_ptr,
+                                                  const uint16_t *__restrict__ r16, int32_t *__restrict__ maxrun)
+{
+    const int b = blockIdx.x, row0 = brow[b];
+    const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+    for (int p = threadIdx.x; p < np; p += 256) {
+        const int s0 = tp[p], s1 = tp[p + 1];
+        int i = s0;
+        while (i < s1) {
+            const int r = r16[i];
+            int j = i + 1;
+            while (j < s1 && r16[j] == r) ++j;
+            if (j - i > e) atomicMax(&maxrun[row0 + r], j - i);
+            i = j;
+        }
+    }
+}
+// pass 2: per bin, the spare sums of its long rows: maxrun[row] becomes the row's first spare slot (-1: none); spare[b] =
+// slots the bin needs (a bin that needs more than kSpare is flagged whole: its tiles go through the fold); nlong[b] = its long rows
+__global__ __launch_bounds__(256) void k_bin_spare(int e, const int32_t *__restrict__ brow, int32_t *__restrict__ maxrun,
+                                                   int32_t *__restrict__ spare, int32_t *__restrict__ nlong)
+{
+    __shared__ int part[256], part2[256];
+    __shared__ int carry, carry2;
+    const int b = blockIdx.x, tid = threadIdx.x, row0 = brow[b], nrows = brow[b + 1] - row0;
+    if (tid == 0) { carry = 0; carry2 = 0; }
+    __syncthreads();
+    for (int r0 = 0; r0 < nrows; r0 += 256) {
+        const int r = r0 + tid;
+        const int m = r < nrows ? maxrun[row0 + r] : 0;
+        const int ex = m > e ? (m + e - 1) / e - 1 : 0;
+        part[tid] = ex;
+        part2[tid] = ex > 0;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int v = tid >= d ? part[tid - d] : 0, v2 = tid >= d ? part2[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            part2[tid] += v2;
+            __syncthreads();
+        }
+        if (r < nrows) maxrun[row0 + r] = ex > 0 ? (carry + part[tid] - ex) | (ex << 16) : -1;   // first slot | slots << 16
+        __syncthreads();
+        if (tid == 255) { carry += part[255]; carry2 += part2[255]; }
+        __syncthreads();
+    }
+    if (tid == 0) { spare[b] = carry; nlong[b] = carry > kSpare ? 0 : carry2; }
+}
+// pass 3: the rows of the products that go to spare sums are rewritten (bins within the budget); the tiles of the others flagged;
+// the bin's list of long rows (row << 16 | first slot, slots) written from lptr[b] on, rows ascending
+__global__ __launch_bounds__(256) void k_bin_rewrite(int np, int e, int rb, const int32_t *__restrict__ brow, const int32_t *__restrict__ tile_ptr,
+                                                     const int32_t *__restrict__ slot, const int32_t *__restrict__ spare,
+                                                     const int32_t *__restrict__ lptr, uint16_t *__restrict__ r16, int32_t *__restrict__ pm,
+                                                     uint32_t *__restrict__ lrow, int32_t *__restrict__ lcnt, int32_t *__restrict__ flagged)
+{
+    __shared__ int cursor;
+    const int b = blockIdx.x, row0 = brow[b], nrows = brow[b + 1] - row0;
+    const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+    const bool over = spare[b] > kSpare;
+    if (over) {                                                     // more long rows than spare sums: every tile with a long run folds
+        for (int p = threadIdx.x; p < np; p += 256) {
+            const int s0 = tp[p], s1 = tp[p + 1];
+            bool hit = false;
+            for (int i = s0; i + e < s1 && !hit; ++i) hit = r16[i] == r16[i + e];
+            if (hit) {
+                pm[(int64_t)b * np + p] |= (int32_t)0x80000000;
+                atomicAdd(flagged, 1);
+            }
+        }
+        return;
+    }
+    if (spare[b] == 0) return;
+    for (int p = threadIdx.x; p < np; p += 256) {
+        const int s0 = tp[p], s1 = tp[p + 1];
+        int i = s0;
+        while (i < s1) {
+            const int r = r16[i];
+            int j = i + 1;
+            while (j < s1 && r16[j] == r) ++j;
+            if (j - i > e) {
+                const int first = slot[row0 + r] & 0xffff;
+                for (int k = i + e; k < j; ++k) r16[k] = (uint16_t)(rb + first + (k - i) / e - 1);
+            }
+            i = j;
+        }
+    }
+    // the list, in row order (one thread: a bin has a handful of long rows)
+    if (threadIdx.x == 0) {
+        int at = lptr[b];
+        for (int r = 0; r < nrows; ++r) {
+            const int w = slot[row0 + r];
+            if (w >= 0) {
+                lrow[at] = ((uint32_t)r << 16) | (uint32_t)(w & 0xffff);
+                lcnt[at] = w >> 16;
+                ++at;
+            }
+        }
+        cursor = at;
+    }
+    (void)cursor;
+}
+
+}  // namespace
+
+void destroy_binned(PanelPlan &p)
+{
+    if (p.d_c16) (void)hipFree(p.d_c16);
+    if (p.d_r16) (void)hipFree(p.d_r16);
+    if (p.d_pm) (void)hipFree(p.d_pm);
+    if (p.d_pbase) (void)hipFree(p.d_pbase);
+    if (p.d_prod) (void)hipFree(p.d_prod);
+    if (p.d_lptr) (void)hipFree(p.d_lptr);
+    if (p.d_lrow) (void)hipFree(p.d_lrow);
+    if (p.d_lcnt) (void)hipFree(p.d_lcnt);
+    p.d_lptr = p.d_lcnt = nullptr;
+    p.d_lrow = nullptr;
+    p.d_c16 = p.d_r16 = nullptr;
+    p.d_pm = p.d_pbase = nullptr;
+    p.d_prod = nullptr;
+    p.binned_mode = false;
+}
+
+// mean nonzeros of a (bin, panel) tile: what a piece of the sum launch can hope to hold
+double binned_tile_nonzeros(const spmv_csr &h, int bin_rows)
+{
+    if (h.rows <= 0 || h.cols <= 0) return 0.0;
+    const double nb = (double)((h.rows + bin_rows - 1) / bin_rows), np = (double)((h.cols + kPw - 1) >> kPwBits);
+    return (double)h.nnz / (nb * np);
+}
+
+// want_rows: 0 = the rule (8192 rows per bin where that still leaves two bins per resident wavefront, else 4096), 4096 | 8192
+int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s)
+{
+    if (want_rows != 0 && want_rows != 1024 && want_rows != 2048 && want_rows != 4096 && want_rows != 8192) {
+        set_error("spmv_csr_plan(panel, binned): rows per bin %d (1024, 2048, 4096 or 8192)", want_rows);
+        return SPMV_ERR_INVALID;
+    }
+    const int64_t np64 = (h.cols + kPw - 1) >> kPwBits;
+    if (np64 > kMaxPanels) {
+        set_error("spmv_csr_plan(panel, binned): %lld columns need more than %d panels of %d columns", (long long)h.cols, kMaxPanels, kPw);
+        return SPMV_ERR_INVALID;
+    }
+    const int np = np64 < 1 ? 1 : (int)np64;
+    if (h.nnz > (int64_t)INT_MAX - 8ll * np - 64) {
+        set_error("spmv_csr_plan(panel, binned): nnz %lld too close to 2^31 for one handle", (long long)h.nnz);
+        return SPMV_ERR_INVALID;
+    }
+    const int cus = device_cus(h.device);
+    int rb = want_rows;
+    if (rb == 0) rb = 4096;     // eight wavefronts per CU (8192: four; measured slower at every size tried: DESIGN.md)
+    p.binned_mode = true;
+    p.bin_rows = rb;
+    p.pw_bits = kPwBits;
+    p.npanels = np;
+    p.splits = 1;
+    if (h.rows == 0) {
+        p.stamp.gen = h.values_gen;
+        p.stamp.have_sum = false;
+        p.ready = true;
+        return SPMV_OK;
+    }
+    // bins: equal nonzero counts, at most rb rows, a whole number of rounds of the wavefronts the sum launch keeps resident
+    // (wavefronts that carry equal loads finish together; the cuts aim at 0.8 rb rows so that hardly any needs splitting)
+    const int64_t slots = (int64_t)cus * ((rb + kSpare + kWave) * 4 * kSumWaves <= 80 * 1024 ? 2 : 1) * kSumWaves;
+    int64_t nb0 = slots * ((h.rows * 5 / 4 + (int64_t)rb * slots - 1) / ((int64_t)rb * slots));
+    if (nb0 > h.rows) nb0 = h.rows;
+    DevPtr<int32_t> brow;
+    int rc = panel_row_blocks(h, nb0, rb, s, brow, &p.nblocks);
+    if (rc) return rc;
+    const int nb = p.nblocks;
+    if ((int64_t)nb * (np + 1) > (int64_t)INT_MAX / 2) {
+        set_error("spmv_csr_plan(panel, binned): %d bins x %d panels is more tiles than the tables hold", nb, np);
+        return SPMV_ERR_INVALID;
+    }
+    DevPtr<int32_t> tiles, pm, pbase, total;
+    DevPtr<uint16_t> rowloc, c16, r16;
+    DevPtr<float> pvals, prod;
+    SPMV_HIP_TRY(tiles.alloc((size_t)nb * (size_t)(np + 1)));
+    SPMV_HIP_TRY(pm.alloc((size_t)nb * (size_t)np));
+    SPMV_HIP_TRY(pbase.alloc((size_t)np + 1));
+    SPMV_HIP_TRY(total.alloc(1));
+    if ((rc = panel_tile_ptr(h, brow.p, nb, kPwBits, np, tiles.p, s))) return rc;
+    k_bin_panel_totals<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, tiles.p, pbase.p);
+    if ((rc = check("k_bin_panel_totals"))) return rc;
+    if ((rc = exclusive_scan_i32(pbase.p, np, total.p, s))) return rc;
+    int32_t padded = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&padded, total.p, sizeof padded, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipMemcpyAsync(pbase.p + np, total.p, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    k_bin_pm<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, tiles.p, pbase.p, pm.p);
+    if ((rc = check("k_bin_pm"))) return rc;
+    const size_t nslot = (size_t)padded + 264;                             // (a piece reads up to 256 entries past a tile's end)
+    SPMV_HIP_TRY(c16.alloc(nslot));
+    SPMV_HIP_TRY(pvals.alloc(nslot));
+    SPMV_HIP_TRY(prod.alloc(nslot));
+    SPMV_HIP_TRY(r16.alloc((size_t)h.nnz + 264));
+    SPMV_HIP_TRY(hipMemsetAsync(r16.p + h.nnz, 0, sizeof(uint16_t) * 264, s));
+    SPMV_HIP_TRY(rowloc.alloc((size_t)h.nnz + 8));
+    SPMV_HIP_TRY(hipMemsetAsync(c16.p, 0, sizeof(uint16_t) * nslot, s));     // (the pad slots of every panel: column 0, value 0)
+    SPMV_HIP_TRY(hipMemsetAsync(pvals.p, 0, sizeof(float) * nslot, s));
+    if (h.nnz > 0) {
+        if ((rc = panel_rowloc(h, brow.p, nb, rowloc.p, s))) return rc;
+        k_bin_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s>>>(nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p,
+                                                                        tiles.p, pm.p, c16.p, pvals.p, r16.p);
+        if ((rc = check("k_bin_fill"))) return rc;
+    }
+    // the product launch: every panel's stream shared by `splits` workgroups so that the launch is at least two rounds of CUs
+    p.splits = np >= 2 * cus ? 1 : (2 * cus + np - 1) / np;
+    if (const char *e = getenv("SPMV_BINNED_SPLITS")) { const int v = atoi(e); if (v > 0) p.splits = v; }
+    // fat tiles (a hundred products or more): four products per lane and piece; thin ones: two
+    p.wide_pieces = (double)h.nnz >= 96.0 * (double)nb * (double)np;
+    if (const char *e = getenv("SPMV_BINNED_WIDE")) { if (*e) p.wide_pieces = atoi(e) != 0; }
+    // rows that hold more products of a tile than a lane takes: spare sums (k_bin_runs); bins with too many of them: the fold
+    int32_t flagged = 0, nlong_total = 0;
+    DevPtr<int32_t> maxrun, spare, lptr, lcnt;
+    DevPtr<uint32_t> lrow;
+    const int e = p.wide_pieces ? 4 : 2;
+    SPMV_HIP_TRY(lptr.alloc((size_t)nb + 1));
+    SPMV_HIP_TRY(hipMemsetAsync(lptr.p, 0, sizeof(int32_t) * ((size_t)nb + 1), s));
+    if (h.nnz > 0) {
+        SPMV_HIP_TRY(maxrun.alloc((size_t)h.rows));
+        SPMV_HIP_TRY(spare.alloc((size_t)nb));
+        SPMV_HIP_TRY(hipMemsetAsync(maxrun.p, 0, sizeof(int32_t) * (size_t)h.rows, s));
+        k_bin_runs<<<dim3((unsigned)nb), dim3(256), 0, s>>>(np, e, brow.p, tiles.p, r16.p, maxrun.p);
+        if ((rc = check("k_bin_runs"))) return rc;
+        k_bin_spare<<<dim3((unsigned)nb), dim3(256), 0, s>>>(e, brow.p, maxrun.p, spare.p, lptr.p);
+        if ((rc = check("k_bin_spare"))) return rc;
+        if ((rc = exclusive_scan_i32(lptr.p, nb, total.p, s))) return rc;
+        SPMV_HIP_TRY(hipMemcpyAsync(&nlong_total, total.p, sizeof nlong_total, hipMemcpyDeviceToHost, s));
+        SPMV_HIP_TRY(hipMemcpyAsync(lptr.p + nb, total.p, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        SPMV_HIP_TRY(hipStreamSynchronize(s));
+    }
+    SPMV_HIP_TRY(lrow.alloc((size_t)nlong_total + 1));
+    SPMV_HIP_TRY(lcnt.alloc((size_t)nlong_total + 1));
+    if (h.nnz > 0) {
+        SPMV_HIP_TRY(hipMemsetAsync(total.p, 0, sizeof(int32_t), s));
+        k_bin_rewrite<<<dim3((unsigned)nb), dim3(256), 0, s>>>(np, e, rb, brow.p, tiles.p, maxrun.p, spare.p, lptr.p, r16.p, pm.p, lrow.p,
+                                                               lcnt.p, total.p);
+        if ((rc = check("k_bin_rewrite"))) return rc;
+        SPMV_HIP_TRY(hipMemcpyAsync(&flagged, total.p, sizeof flagged, hipMemcpyDeviceToHost, s));
+    }
+    if ((rc = stamp_values(h, s, p.stamp))) return rc;
+    SPMV_HIP_TRY(hipStreamSynchronize(s));   // the temporaries are freed on return
+    p.padded = padded;
+    p.flagged_tiles = flagged;
+    p.long_rows = nlong_total;
+    p.d_lptr = lptr.release();
+    p.d_lrow = lrow.release();
+    p.d_lcnt = lcnt.release();
+    p.d_c16 = c16.release();
+    p.d_pvals = pvals.release();
+    p.d_prod = prod.release();
+    p.d_r16 = r16.release();
+    p.d_pm = pm.release();
+    p.d_pbase = pbase.release();
+    p.d_tile_ptr = tiles.release();
+    p.d_brow = brow.release();
+    p.ready = true;
+    return SPMV_OK;
+}
+
+template <int RB, int E>
+static int launch_sums_e(const spmv_csr &h, const PanelPlan &p, float *y, hipStream_t s)
+{
+    const size_t lds = sizeof(float) * (size_t)(RB + kSpare + kWave) * kSumWaves;
+    const dim3 grid((unsigned)((p.nblocks + kSumWaves - 1) / kSumWaves)), block(kSumWaves * kWave);
+    static LdsOptIn optin;
+    if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_bin_sums<RB, E>), h.device, (int)lds)) return rc;
+    k_bin_sums<RB, E><<<grid, block, lds, s>>>(p.nblocks, p.npanels, p.d_brow, p.d_tile_ptr, p.d_pm, p.d_r16, p.d_prod, p.d_lptr,
+                                               p.d_lrow, p.d_lcnt, y);
+    return check("k_bin_sums");
+}
+template <int RB>
+static int launch_sums(const spmv_csr &h, const PanelPlan &p, float *y, hipStream_t s)
+{
+    return p.wide_pieces ? launch_sums_e<RB, 4>(h, p, y, s) : launch_sums_e<RB, 2>(h, p, y, s);
+}
+
+int launch_binned(const spmv_csr &h, const PanelPlan &p, const float *x, float *y, hipStream_t s)
+{
+    if (p.nblocks == 0) return SPMV_OK;   // no rows
+    {
+        const size_t lds = sizeof(float) * (size_t)kPw;
+        static LdsOptIn optin;
+        if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_bin_products), h.device, (int)lds)) return rc;
+        k_bin_products<<<dim3((unsigned)(p.npanels * p.splits)), dim3(kProdThreads), lds, s>>>(p.splits, h.cols, p.d_pbase, p.d_c16,
+                                                                                               p.d_pvals, x, p.d_prod);
+        if (int rc = check("k_bin_products")) return rc;
+    }
+    return p.bin_rows == 8192 ? launch_sums<8192>(h, p, y, s) : p.bin_rows == 4096 ? launch_sums<4096>(h, p, y, s) :
+           p.bin_rows == 2048 ? launch_sums<2048>(h, p, y, s) : launch_sums<1024>(h, p, y, s);
+}
+
+}  // namespace spmv

@@ -500,8 +500,18 @@ int panel_rowloc(const spmv_csr &h, const int32_t *d_brow, int nblocks, uint16_t
     return check_launch("k_panel_rowloc");
 }
 
+// tile_ptr[b * (np + 1) + p] = first position, in block-major / panel-minor order, of the nonzeros of row block b whose
+// column lies in panel p (np <= 4096 panels of 2^pw_bits columns); entry np = end of the block.  Shared with kernels_binned.hip.
+int panel_tile_ptr(const spmv_csr &h, const int32_t *d_brow, int nblocks, int pw_bits, int np, int32_t *d_tile_ptr, hipStream_t s)
+{
+    if (np > kMaxPanels) { set_error("panel_tile_ptr: %d panels (at most %d)", np, kMaxPanels); return SPMV_ERR_INVALID; }
+    k_panel_tiles<<<dim3((unsigned)nblocks), dim3(256), 0, s>>>(d_brow, h.d_row_ptr, h.d_col_idx, pw_bits, np, d_tile_ptr);
+    return check_launch("k_panel_tiles");
+}
+
 void destroy_panel(PanelPlan &p)
 {
+    destroy_binned(p);
     destroy_colsort(p);
     if (p.d_packed) (void)hipFree(p.d_packed);
     if (p.d_pvals) (void)hipFree(p.d_pvals);
@@ -523,6 +533,7 @@ int refresh_panel(spmv_csr &h, PanelPlan &dst, hipStream_t s)
 {
     if (!dst.ready) return build_panel(h, dst, 0, 0, 0, s);
     if (dst.stamp.gen == h.values_gen) return SPMV_OK;
+    if (dst.binned_mode) return build_panel(h, dst, dst.bin_rows, 0, 4, s);
     if (dst.sorted_mode) return build_panel(h, dst, dst.sb_rows, dst.sb_waves, 3, s);
     return build_panel(h, dst, dst.pw_bits, dst.waves_per_launch, dst.lds_mode ? 2 : 1, s);
 }
@@ -533,11 +544,18 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, h
 }
 
 // want_mode: 0 = the rule below, 1 = panels through L2 (k_panel), 2 = panels staged in LDS (k_panel_lds),
-//            3 = sorted blocks (kernels_colsort.hip; SPMV_PANEL_SORTED=1 makes it the rule's answer)
+//            3 = sorted blocks (kernels_colsort.hip; SPMV_PANEL_SORTED=1 makes it the rule's answer),
+//            4 = binned (kernels_binned.hip: products streamed in panel order, summed per row block; want_bits = rows per bin)
 int build_panel(spmv_csr &h, PanelPlan &dst, int want_bits, int want_waves, int want_mode, hipStream_t s)
 {
     destroy_panel(dst);
     PanelPlan p;
+    if (want_mode == 4) {      // binned: two streaming launches, no gather from memory (kernels_binned.hip)
+        const int rc = plan_binned(h, p, want_bits, s);
+        if (rc) { destroy_panel(p); return rc; }
+        dst = p;
+        return SPMV_OK;
+    }
     {
         bool sorted = false;
         if (const char *e = getenv("SPMV_PANEL_SORTED")) sorted = atoi(e) != 0;
@@ -653,6 +671,7 @@ int build_panel(spmv_csr &h, PanelPlan &dst, int want_bits, int want_waves, int 
 
 int panel_launches(const PanelPlan &p)
 {
+    if (p.binned_mode) return p.nblocks ? 2 : 0;
     if (p.lds_mode || p.sorted_mode) return p.nblocks ? 1 : 0;
     return p.nblocks && p.waves_per_launch ? (p.nblocks + p.waves_per_launch - 1) / p.waves_per_launch : 0;
 }
@@ -666,6 +685,7 @@ int launch_panel_plan(const spmv_csr &h, const PanelPlan &p, const float *x, flo
         return SPMV_ERR_NOT_PLANNED;
     }
     if (int rc = require_fresh_values(h, p.stamp, s, "panel")) return rc;
+    if (p.binned_mode) return launch_binned(h, p, x, y, s);
     if (p.sorted_mode) return launch_colsort(h, p, x, y, s);
     if (p.lds_mode) {
         if (p.nblocks == 0) return SPMV_OK;

@@ -124,6 +124,24 @@ struct PanelPlan {
     int64_t units = 0;
     int64_t lines = 0;             // occupied 128-byte lines of x, summed over the blocks (plan statistic)
     int64_t tail = 0;              // nonzeros in the tails (long rows, what could not be grouped)
+    // binned (mode 4, kernels_binned.hip): the nonzeros twice over -- in PANEL-major order (d_c16 + d_pvals: what the
+    // product launch streams, its panel of x in LDS) and in BIN-major order (d_r16: what the sum launch streams beside the
+    // products); tile (bin b, panel p) is contiguous in both, rows ascending inside it
+    bool binned_mode = false;
+    int bin_rows = 0;              // most rows of a bin (4096 | 8192): a wavefront's private sums in LDS
+    uint16_t *d_c16 = nullptr;     // [padded] column - panel * 2^pw_bits, panel-major (every panel padded to a multiple of 8)
+    uint16_t *d_r16 = nullptr;     // [nnz] row - brow[bin], bin-major (d_tile_ptr positions)
+    int32_t *d_pm = nullptr;       // [nblocks * npanels] panel-major position of tile (b, p)
+    int32_t *d_pbase = nullptr;    // [npanels + 1] panel-major position of every panel's first entry
+    float *d_prod = nullptr;       // [padded] scratch of a run: the products, panel-major
+    int64_t padded = 0;            // entries of the panel-major arrays
+    int splits = 1;                // workgroups per panel of the product launch
+    bool wide_pieces = false;      // the sum launch takes four products per lane (fat tiles) instead of two
+    int flagged_tiles = 0;         // tiles that go through the fold (bins whose long rows need more spare sums than there are)
+    int long_rows = 0;             // rows with spare sums (more products in some tile than a lane takes)
+    int32_t *d_lptr = nullptr;     // [nblocks + 1] first long row of every bin in d_lrow / d_lcnt
+    uint32_t *d_lrow = nullptr;    // [long_rows] row in bin << 16 | first spare slot
+    int32_t *d_lcnt = nullptr;     // [long_rows] spare slots of the row
 };
 
 // SPMV_XSKIP (kernels_xskip.hip): the matrix in input-major segments per block of 1024 outputs
@@ -219,6 +237,12 @@ double colsort_cost(int rows_per_block, double lines_per_nnz, double tail_frac);
 int colsort_probe(const spmv_csr &h, hipStream_t s, double *long_frac, double *wide_frac, double *lines_per_nnz);
 int launch_colsort(const spmv_csr &h, const PanelPlan &p, const float *x, float *y, hipStream_t s);
 void destroy_colsort(PanelPlan &p);
+// kernels_binned.hip: SPMV_PANEL mode 4
+int panel_tile_ptr(const spmv_csr &h, const int32_t *d_brow, int nblocks, int pw_bits, int np, int32_t *d_tile_ptr, hipStream_t s);
+int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s);
+int launch_binned(const spmv_csr &h, const PanelPlan &p, const float *x, float *y, hipStream_t s);
+void destroy_binned(PanelPlan &p);
+double binned_tile_nonzeros(const spmv_csr &h, int bin_rows);
 void destroy_plans(spmv_csr &h);
 void drop_tiled_plan(spmv_csr &h);   // SPMV_AUTO resolved to another variant: the TILED plan it looked at is released
 
