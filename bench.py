@@ -551,8 +551,8 @@ def rate_fields(prefix, hbm_bytes, algorithmic, ms):
 
 def l2_roofline(plan_text, nnz, ms):
     """The panel family is bound by L2 line requests, not by HBM bytes: a second roofline with that ceiling."""
-    if not ("auto -> panel" in plan_text or plan_text.startswith(("panel_columns", "sorted_blocks"))):
-        return {}
+    if "binned" in plan_text or not ("auto -> panel" in plan_text or plan_text.startswith(("panel_columns", "sorted_blocks"))):
+        return {}          # (the binned layout gathers nothing from memory: two streaming launches, HBM-bound)
     if "lines_per_nonzero=" in plan_text:
         lines = float(plan_text.split("lines_per_nonzero=")[1].split()[0]) * nnz
         what = "lines_per_nonzero of the plan x nonzeros (distinct 128-byte lines of x per block, each requested about once)"
@@ -569,7 +569,7 @@ def dominant_kernel(resolved, plan_now):
     def _n(key):
         return int(plan_now.split(key + "=")[1].split()[0]) if key + "=" in plan_now else 0
     if resolved == "panel":
-        return "k_colsort" if "sorted_blocks=" in plan_now else "k_panel"
+        return "k_bin_products + k_bin_sums" if "binned" in plan_now else "k_colsort" if "sorted_blocks=" in plan_now else "k_panel"
     if resolved == "tiled" and (_n("col16_chunks") or _n("sorted_chunks")):
         # one launch: all chunks 16-bit -> k_tiled16, all sorted -> k_sorted, otherwise the three bodies in k_tiled_mixed
         return ("k_tiled16" if _n("col16_chunks") == _n("chunks") else

@@ -124,11 +124,15 @@ def test_all_variants_agree_on_every_row(c4, pkg):
 
 
 def test_auto_choice_at_full_size(c4, pkg):
-    """SPMV_AUTO at the BASELINE sizes: the LDS-tiled kernel on a band of 8192 columns, the panel sweep on uniform
-    columns, the sorted blocks of the panel family on a band of 1M columns (65 536: whichever the models price lower)."""
+    """SPMV_AUTO at the BASELINE sizes: the LDS-tiled kernel on a band of 8192 columns; on uniform columns the binned layout
+    of the panel family (round 4: two streaming launches) where a (bin, panel) tile still holds dozens of nonzeros -- config
+    4 -- and the panel sweep where it holds ten -- config 5's shard, 128Mi columns; the sorted blocks of the panel family on
+    a band of 1M columns (65 536: whichever the models price lower)."""
     d = c4["A"].plan_describe(pkg.capi.AUTO)
     band = c4["w"].band
-    if band == 0:
+    if band == 0 and c4["w"].cols == c4["w"].rows and c4["A"].rows == c4["w"].rows:
+        assert d.startswith("auto -> panel: binned bins="), d
+    elif band == 0:
         assert d.startswith("auto -> panel: panel_columns="), d
     elif band <= 8192:
         assert d.startswith("auto -> tiled"), d
