@@ -47,11 +47,13 @@ void wsp_sm_gemv_gpu(int M, int N, float *A_host, float *X_host, float *Y_host);
 // expression, timed with two events and printed as "<stringified call> took <ms> ms").  Here the launch expression
 // is one of the spmv_*_run_host calls, which time their kernel between two HIP events on the launch stream
 // themselves and report it through their last argument; by convention that argument is a float named
-// `kernel_ms` in the calling scope.
+// `kernel_ms` in the calling scope.  The reference's figure is ONE COLD launch (module load included): the run_host calls
+// keep the event time of their first launch too and the line prints it after the warm figure.
 #define TIME_KERNEL(kernel_call)                                                     \
     {                                                                                \
         SPMV_CHECK(kernel_call);                                                     \
-        std::cout << #kernel_call << " took " << kernel_ms << " ms" << std::endl;    \
+        std::cout << #kernel_call << " took " << kernel_ms << " ms (first launch, cold, as the reference times it: " \
+                  << spmv_last_first_launch_ms() << " ms)" << std::endl;                                             \
     }
 
 // the reference's name for the error macro (kernel.hpp:21-28), for code written against that header

@@ -103,6 +103,14 @@ SPMV_API int spmv_dist_pipe_exchange_only(spmv_dist_pipe_t *p, float *d_y_full, 
  * caller).  Not for SPMV_DIST_ALLGATHER. */
 SPMV_API int spmv_dist_pipe_set_footprint(spmv_dist_pipe_t *p, const int64_t *need_lo, const int64_t *need_hi, int per_rank);
 SPMV_API int spmv_dist_pipe_finish(spmv_dist_pipe_t *p, void *stream);
+/* SPMV_DIST_PEER_STORE only (a no-op for the RCCL exchanges, whose receives a rank enqueues itself behind its own work):
+ * the OTHER ranks write this rank's y_full, so the readers of one step's y_full -- a norm, the copy that makes y the next x,
+ * enqueued on `stream` after spmv_dist_pipe_finish -- have to be ordered before the peers' stores of the next step.
+ * spmv_dist_pipe_release marks that point of `stream`; every store a peer enqueues into this rank's y_full AFTER the call
+ * waits for it.  spmv_dist_pipe_step sets the mark itself at its start, which covers callers that step the ranks
+ * concurrently (one host thread per rank); a caller that steps the ranks of a process one after the other calls
+ * spmv_dist_pipe_release on EVERY rank (readers enqueued) before the first rank's next step -- or double-buffers y_full. */
+SPMV_API int spmv_dist_pipe_release(spmv_dist_pipe_t *p, void *stream);
 SPMV_API int spmv_dist_pipe_destroy(spmv_dist_pipe_t *p);
 
 /* Ranks WITHOUT an RCCL communicator, for SPMV_DIST_PEER_STORE only: one process drives them all; `devices` may name one

@@ -106,6 +106,10 @@ enum spmv_variant {
 SPMV_API int spmv_device_count(void);            /* >= 0; 0 when no HIP device is usable */
 SPMV_API const char *spmv_last_error(void);      /* thread-local, never NULL             */
 SPMV_API const char *spmv_variant_name(int variant);
+/* The event time of the FIRST launch of the last spmv_*_run_host call on this thread: cold, code-object load and first-touch
+ * included -- the figure the reference's TIME_KERNEL prints (kernel.hpp:31-48 times one cold launch).  *kernel_ms of those
+ * calls is the second, warm launch.  The launchers of include/kernel.hpp print both. */
+SPMV_API float spmv_last_first_launch_ms(void);
 
 /* ---- matrix handles ---------------------------------------------------
  * replaces: CSRMatrix (src/matrix_csr.cpp:5-23, src/include/matrix_csr.hpp:4-25)

@@ -35,6 +35,7 @@ SIGNATURES = {
     "spmv_device_count": (C.c_int, []),
     "spmv_last_error": (C.c_char_p, []),
     "spmv_variant_name": (C.c_char_p, [C.c_int]),
+    "spmv_last_first_launch_ms": (C.c_float, []),
     "spmv_csr_create_host": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, _i32p, _i32p, _f32p, _HP]),
     "spmv_csr_create_device": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, _i32p, _i32p, _f32p, _HP]),
     "spmv_csr_from_dense_host": (C.c_int, [C.c_int, C.c_int, _f32p, _vp, _HP]),

@@ -40,6 +40,7 @@ SIGNATURES = {
     "spmv_dist_pipe_exchange_only": (C.c_int, [_vp, _vp, _vp]),
     "spmv_dist_pipe_set_footprint": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
     "spmv_dist_pipe_finish": (C.c_int, [_vp, _vp]),
+    "spmv_dist_pipe_release": (C.c_int, [_vp, _vp]),
     "spmv_dist_pipe_destroy": (C.c_int, [_vp]),
 }
 
@@ -127,6 +128,10 @@ class NativePipeline:
     def finish(self):
         check(lib().spmv_dist_pipe_finish(self._p, capi._stream_handle()))
         return self.y_full
+
+    def release(self) -> None:
+        """The readers of y_full enqueued so far come before the peers' stores of the next step (peer stores only)."""
+        check(lib().spmv_dist_pipe_release(self._p, capi._stream_handle()))
 
     def close(self) -> None:
         if self._p:

@@ -31,6 +31,11 @@ struct spmv_dist_pipe {
     hipStream_t comm = nullptr;
     std::vector<hipEvent_t> ev_mult, ev_done;
     std::vector<char> pending;     // ev_done[s] has been recorded at least once
+    // PEER_STORE: the OTHER ranks write this rank's y_full.  ev_release marks the point of this rank's stream behind which the
+    // readers of the last step's y_full lie (spmv_dist_pipe_release, or the start of this rank's own next step): a peer's
+    // stores of the next step wait for it.
+    hipEvent_t ev_release = nullptr;
+    bool released = false;
     // PEER_STORE (spmv_dist_pipe_link): every rank's pipe and y_full, index = rank
     std::vector<spmv_dist_pipe *> peers;
     std::vector<float *> peer_y;
@@ -266,6 +271,7 @@ int spmv_dist_pipe_create(spmv_dist_t *d, int S, int64_t sub_rows, int64_t cols,
         e = hipEventCreateWithFlags(&p->ev_mult[s], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_done[s], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_release, hipEventDisableTiming);
     if (e != hipSuccess) {
         (void)spmv_dist_pipe_destroy(p);
         return fail(SPMV_ERR_HIP, "spmv_dist_pipe_create: %s", hipGetErrorString(e));
@@ -378,9 +384,11 @@ int exchange_group(spmv_dist_pipe *p, int s, float *d_y_full)
             if (p->peer_y[d->rank] != d_y_full) return fail(SPMV_ERR_INVALID, "SPMV_DIST_PEER_STORE: y_full differs from the linked buffer");
             for (int k = 1; k < world; ++k) {   // start with the next rank: the owners do not all hit one peer at once
                 const int q = (d->rank + k) % world;
-                for (int k = 0; k < needed_parts(p); ++k) {
+                // q's readers of the previous step's y_full come first (its release mark, if it has set one)
+                if (p->peers[q]->released) DIST_HIP(hipStreamWaitEvent(p->comm, p->peers[q]->ev_release, 0));
+                for (int part = 0; part < needed_parts(p); ++part) {
                     int64_t a, b;
-                    needed_part(p, s, d->rank, q, k, &a, &b);   // (the whole slot without a footprint)
+                    needed_part(p, s, d->rank, q, part, &a, &b);   // (the whole slot without a footprint)
                     if (b > a)
                         DIST_HIP(hipMemcpyPeerAsync(p->peer_y[q] + a, p->peers[q]->d->device, d_y_full + a, d->device,
                                                     (size_t)(b - a) * sizeof(float), p->comm));
@@ -399,6 +407,13 @@ int spmv_dist_pipe_step(spmv_dist_pipe_t *p, spmv_csr_t *const *blocks, int vari
     spmv_dist *d = p->d;
     if (int rc = require_device(d, "spmv_dist_pipe_step")) return rc;
     hipStream_t st = (hipStream_t)stream;
+    // peer stores: whatever this rank's stream holds so far (the readers of the last step's y_full) precedes the stores the
+    // peers enqueue from here on.  (A peer whose step was enqueued BEFORE this call could not wait for it: where the
+    // ranks of one process are stepped one after the other, spmv_dist_pipe_release on every rank first closes that gap.)
+    if (p->exchange == SPMV_DIST_PEER_STORE && d->world > 1) {
+        DIST_HIP(hipEventRecord(p->ev_release, st));
+        p->released = true;
+    }
     for (int s = 0; s < p->S; ++s) {
         int64_t rows = 0, cols = 0;
         if (!blocks[s] || spmv_csr_dims(blocks[s], &rows, &cols, nullptr) != SPMV_OK || rows != p->sub_rows || cols != p->cols)
@@ -455,6 +470,16 @@ int spmv_dist_pipe_finish(spmv_dist_pipe_t *p, void *stream)
     return SPMV_OK;
 }
 
+int spmv_dist_pipe_release(spmv_dist_pipe_t *p, void *stream)
+{
+    if (!p) return fail(SPMV_ERR_INVALID, "spmv_dist_pipe_release: null handle");
+    if (int rc = require_device(p->d, "spmv_dist_pipe_release")) return rc;
+    if (p->exchange != SPMV_DIST_PEER_STORE || p->d->world == 1) return SPMV_OK;   // RCCL: the receives are enqueued by this rank itself
+    DIST_HIP(hipEventRecord(p->ev_release, (hipStream_t)stream));
+    p->released = true;
+    return SPMV_OK;
+}
+
 int spmv_dist_pipe_destroy(spmv_dist_pipe_t *p)
 {
     if (!p) return SPMV_OK;
@@ -464,6 +489,7 @@ int spmv_dist_pipe_destroy(spmv_dist_pipe_t *p)
     if (p->comm) (void)hipStreamSynchronize(p->comm);
     for (hipEvent_t e : p->ev_mult) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->ev_done) if (e) (void)hipEventDestroy(e);
+    if (p->ev_release) (void)hipEventDestroy(p->ev_release);
     if (p->comm) (void)hipStreamDestroy(p->comm);
     (void)hipSetDevice(prev);
     delete p;

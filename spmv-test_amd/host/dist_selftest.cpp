@@ -3,7 +3,7 @@
 // matrix multiplied by a single handle.  Also the worked example of INTEGRATION.md for a C++ caller.
 //
 //   spmv_dist_selftest [--ranks N] [--rows-per-rank R] [--band B] [--unequal] [--variant tiled|adaptive|scalar|auto] [--steps K]
-//                      [--pipeline S] [--exchange allgather|p2p|peer] [--local] [--footprint] [--no-verify]
+//                      [--pipeline S] [--exchange allgather|p2p|peer] [--local] [--footprint] [--no-verify] [--vary-x]
 // N defaults to the number of visible GPUs.  Matrix: (N*R)^2, 16 nonzeros per row (config 2's law), generated on
 // the devices by spmv_synth_fill; with --unequal the blocks hold R-17, R+17, ... rows (the all-gather-v path).
 // --pipeline S (round 3): the pipelined step of spmv_dist.h -- every rank's R rows as S block-cyclic blocks, the exchange
@@ -11,6 +11,10 @@
 // peer, or peer stores (hipMemcpyPeerAsync, no RCCL).  --local: ranks without a communicator (spmv_dist_init_local), as
 // many as asked on the visible devices round-robin -- the whole pipeline with world > 1 on a ONE-GPU box (peer stores only).
 // --footprint: the optional footprint exchange -- every rank receives only the rows of y its own columns reference.
+// --vary-x (with --pipeline, verified runs): four more steps with x doubled from step to step, a slow reader of y_full
+// on every rank's stream between the steps (a copy behind a large fill) and spmv_dist_pipe_release before the next step:
+// every snapshot must equal 2^t times the single-handle y, bit for bit -- the peer stores of step t+1 may not overtake the
+// readers of step t.
 // --no-verify (with --pipeline): timing only, no single-handle reference -- the whole matrix of 8 x 16Mi rows has 2^31
 // nonzeros, one more than a handle takes (bench.py --exchange all times the peer-store pipeline at that size).
 // Prints one JSON line; exit code 0 iff every rank's y is bit-identical to the single-handle result.
@@ -50,13 +54,13 @@ struct Rank {
     spmv_dist_pipe_t *pipe = nullptr;
 };
 
-static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint, bool verify);
+static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint, bool verify, bool vary_x);
 
 int main(int argc, char **argv)
 {
     int ndev = spmv_device_count();
     int64_t per = 1 << 18, band = 4096;
-    bool unequal = false, local = false, footprint = false, verify = true;
+    bool unequal = false, local = false, footprint = false, verify = true, vary_x = false;
     int variant = SPMV_TILED, steps = 20, pipeline = 0, exchange = SPMV_DIST_ALLGATHER;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -69,6 +73,7 @@ int main(int argc, char **argv)
         else if (a == "--local") local = true;
         else if (a == "--footprint") footprint = true;
         else if (a == "--no-verify") verify = false;
+        else if (a == "--vary-x") vary_x = true;
         else if (a == "--pipeline") pipeline = atoi(next());
         else if (a == "--exchange") {
             std::string v = next();
@@ -84,7 +89,7 @@ int main(int argc, char **argv)
     }
     if (ndev < 1 || (!local && ndev > spmv_device_count())) { fprintf(stderr, "HIP error: %d ranks asked, %d devices visible\n", ndev, spmv_device_count()); return EXIT_FAILURE; }
     if (local && spmv_device_count() < 1) { fprintf(stderr, "HIP error: no device visible\n"); return EXIT_FAILURE; }
-    if (pipeline > 0) return run_pipeline(ndev, per, band, variant, steps, pipeline, exchange, local, footprint, verify);
+    if (pipeline > 0) return run_pipeline(ndev, per, band, variant, steps, pipeline, exchange, local, footprint, verify, vary_x);
     if (local) { fprintf(stderr, "--local needs --pipeline S --exchange peer\n"); return 2; }
     const uint64_t seed = 20251031;
     const int64_t rows = per * ndev, cols = rows;
@@ -222,7 +227,7 @@ int main(int argc, char **argv)
 
 
 // ---- the pipelined step: S block-cyclic blocks per rank, exchange of group s under the multiply of block s+1 ------------
-static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint, bool verify)
+static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int steps, int S, int exchange, bool local, bool footprint, bool verify, bool vary_x)
 {
     if (footprint && exchange == SPMV_DIST_ALLGATHER) { fprintf(stderr, "--footprint needs --exchange p2p or peer\n"); return 2; }
     if (S < 1 || per % S) { fprintf(stderr, "--rows-per-rank must be a multiple of --pipeline\n"); return 2; }
@@ -361,6 +366,66 @@ static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int st
         }
     }
 
+    // --vary-x: x doubles from step to step, y_full is read (slowly) between the steps; the stores of the next step wait
+    int64_t vary_bad = -1;
+    if (vary_x && verify && !footprint) {
+        vary_bad = 0;
+        constexpr int T = 4;
+        std::vector<float> x0(cols), yref_h(rows), snap_h(rows);
+        std::vector<std::vector<float>> xt(T, std::vector<float>(cols));     // one host buffer per step: the uploads are asynchronous
+        OK_HIP(hipSetDevice(rk[0].device));
+        OK_HIP(hipMemcpy(x0.data(), rk[0].d_x, sizeof(float) * cols, hipMemcpyDeviceToHost));
+        {   // the single-handle y for x0 (the verify block above left it on the host only inside its scope: recompute)
+            float *d_yr = nullptr;
+            OK_HIP(hipMalloc((void **)&d_yr, sizeof(float) * rows));
+            OK_SPMV(spmv_csr_run(whole, variant, rk[0].d_x, d_yr, rk[0].stream));
+            OK_HIP(hipStreamSynchronize(rk[0].stream));
+            OK_HIP(hipMemcpy(yref_h.data(), d_yr, sizeof(float) * rows, hipMemcpyDeviceToHost));
+            OK_HIP(hipFree(d_yr));
+        }
+        const size_t ballast = (size_t)256 << 20;
+        std::vector<float *> snaps((size_t)ndev * T, nullptr);
+        std::vector<void *> fill(ndev, nullptr);
+        for (int r = 0; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            OK_HIP(hipMalloc(&fill[r], ballast));
+            for (int t = 0; t < T; ++t) OK_HIP(hipMalloc((void **)&snaps[(size_t)r * T + t], sizeof(float) * rows));
+        }
+        finish_all();
+        for (int t = 0; t < T; ++t) {
+            const float scale = (float)(1 << t);
+            for (int64_t i = 0; i < cols; ++i) xt[t][i] = x0[i] * scale;
+            for (int r = 0; r < ndev; ++r) {
+                OK_HIP(hipSetDevice(rk[r].device));
+                OK_HIP(hipMemcpyAsync(rk[r].d_x, xt[t].data(), sizeof(float) * cols, hipMemcpyHostToDevice, rk[r].stream));
+            }
+            step();
+            for (int r = 0; r < ndev; ++r) { OK_HIP(hipSetDevice(rk[r].device)); OK_SPMV(spmv_dist_pipe_finish(rk[r].pipe, rk[r].stream)); }
+            for (int r = 0; r < ndev; ++r) {          // the slow reader of this step's y_full, then the release mark
+                OK_HIP(hipSetDevice(rk[r].device));
+                OK_HIP(hipMemsetAsync(fill[r], t, ballast, rk[r].stream));
+                OK_HIP(hipMemcpyAsync(snaps[(size_t)r * T + t], rk[r].d_y, sizeof(float) * rows, hipMemcpyDeviceToDevice, rk[r].stream));
+                OK_SPMV(spmv_dist_pipe_release(rk[r].pipe, rk[r].stream));
+            }
+        }
+        finish_all();
+        for (int r = 0; r < ndev; ++r) {
+            OK_HIP(hipSetDevice(rk[r].device));
+            for (int t = 0; t < T; ++t) {
+                OK_HIP(hipMemcpy(snap_h.data(), snaps[(size_t)r * T + t], sizeof(float) * rows, hipMemcpyDeviceToHost));
+                const float scale = (float)(1 << t);
+                for (int64_t i = 0; i < rows; ++i) {
+                    const float want = yref_h[i] * scale;
+                    vary_bad += std::memcmp(&snap_h[i], &want, sizeof(float)) != 0;
+                }
+                OK_HIP(hipFree(snaps[(size_t)r * T + t]));
+            }
+            OK_HIP(hipFree(fill[r]));
+            OK_HIP(hipMemcpy(rk[r].d_x, x0.data(), sizeof(float) * cols, hipMemcpyHostToDevice));
+        }
+        differing += vary_bad;
+    }
+
     hipEvent_t e0, e1;
     OK_HIP(hipSetDevice(rk[0].device));
     OK_HIP(hipEventCreate(&e0));
@@ -398,11 +463,12 @@ static int run_pipeline(int ndev, int64_t per, int64_t band, int variant, int st
     const char *xname = exchange == SPMV_DIST_ALLGATHER ? "allgather" : exchange == SPMV_DIST_P2P ? "p2p" : "peer";
     printf("{\"world\": %d, \"process_model\": \"%s\", \"pipeline_blocks_per_rank\": %d, \"exchange\": \"%s\", \"rows\": %lld, "
            "\"nnz\": %lld, \"band\": %lld, \"variant\": \"%s\", \"footprint_exchange\": %s, \"rows_never_sent_to_a_rank_that_does_not_need_them\": %lld, "
-           "\"rows_differing_from_single_handle\": %lld, \"verified\": %s, \"step_ms\": %.5f, "
+           "\"rows_differing_from_single_handle\": %lld, \"verified\": %s, \"vary_x_snapshot_words_differing\": %lld, \"step_ms\": %.5f, "
            "\"multiply_only_ms\": %.5f, \"exchange_only_ms\": %.5f, \"aggregate_GBs\": %.1f, \"plan\": \"%s\"}\n",
            ndev, local ? "one process, local ranks (no communicator), devices round-robin" : "one process, ncclCommInitAll", S, xname,
            (long long)rows, (long long)nnz_all, (long long)band, spmv_variant_name(variant), footprint ? "true" : "false",
-           (long long)untouched, (long long)differing, verify ? "true" : "false", step_ms, mult_ms, xchg_ms, bytes / (step_ms * 1e-3) / 1e9, plan);
+           (long long)untouched, (long long)differing, verify ? "true" : "false", (long long)vary_bad, step_ms, mult_ms, xchg_ms,
+           bytes / (step_ms * 1e-3) / 1e9, plan);
     for (int r = 0; r < ndev; ++r) {
         OK_HIP(hipSetDevice(rk[r].device));
         (void)spmv_dist_pipe_destroy(rk[r].pipe);

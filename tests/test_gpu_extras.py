@@ -275,7 +275,12 @@ def test_dist_selftest_world_of_one_gpu(pkg, gpu):
      "--rows-per-rank", str(1 << 20)],
     ["--local", "--ranks", "4", "--pipeline", "4", "--exchange", "peer", "--footprint", "--band", "8192"],   # the optional footprint exchange
     ["--pipeline", "2", "--exchange", "p2p", "--footprint"],
-], ids=["allgather", "p2p-auto", "peer-4ranks", "peer-3ranks", "peer-sorted-blocks", "peer-footprint", "p2p-footprint"])
+    # x doubled from step to step, a slow reader of y_full between the steps, spmv_dist_pipe_release before the next step:
+    # the peers' stores of step t+1 wait for the readers of step t
+    ["--local", "--ranks", "4", "--pipeline", "4", "--exchange", "peer", "--vary-x"],
+    ["--pipeline", "4", "--exchange", "allgather", "--vary-x"],
+], ids=["allgather", "p2p-auto", "peer-4ranks", "peer-3ranks", "peer-sorted-blocks", "peer-footprint", "p2p-footprint",
+        "peer-vary-x", "allgather-vary-x"])
 def test_dist_pipeline_selftest(pkg, gpu, args):
     """The pipelined step of include/spmv_dist.h from C++: S block-cyclic row blocks per rank, the
     exchange of block group s on a side stream under the multiply of block s+1, three steps back to back, every rank's y
@@ -294,6 +299,8 @@ def test_dist_pipeline_selftest(pkg, gpu, args):
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["rows_differing_from_single_handle"] == 0 and out["step_ms"] > 0
+    if "--vary-x" in args:
+        assert out["vary_x_snapshot_words_differing"] == 0
     if "--local" in args:
         assert out["world"] == int(args[args.index("--ranks") + 1]) and out["exchange"] == "peer"
     if "--footprint" in args and out["world"] > 1:
