@@ -57,8 +57,15 @@ enum spmv_variant {
                         /*   csr_naive_kernel      src/kernels/csr_naive.cu:6-23   */
                         /*   (bit-identical to SgemvCPU, src/tester.cpp:36-45).    */
                         /* Shares SPMV_WAVE_PIPE's plan (operands only; see there). */
-    SPMV_WAVE = 1,      /* one 64-lane wavefront per row, __shfl_down reduction:   */
+    SPMV_WAVE = 1,      /* 64-lane wavefronts + __shfl_down reduction:             */
                         /*   wsp_kernel_v0         src/kernels/wsp.cu:4-56         */
+                        /* Rows of mean > 32 nonzeros: a wavefront per row.  Shorter */
+                        /* rows (round 4): a wavefront per 64 rows as in            */
+                        /* SPMV_WAVE_PIPE -- coalesced streams, a lane per short row, */
+                        /* the wave + __shfl_down per longer one, the longest in     */
+                        /* pieces -- but x gathered from memory: no window in LDS,   */
+                        /* no 16-bit offsets (the plain kernel of the pair).  Shares */
+                        /* SPMV_WAVE_PIPE's plan there (the long rows' pieces).      */
     SPMV_WAVE_PIPE = 2, /* a wavefront per 64 rows: their nonzeros streamed        */
                         /* coalesced with all loads of a run in flight, products    */
                         /* parked in LDS, a lane per short row, the wave +          */
@@ -153,8 +160,8 @@ SPMV_API int spmv_csr_destroy(spmv_csr_t *h);
  * spmv_csr_plan: one-off device-side preprocessing a variant needs (chunk
  * boundaries, column windows, for SPMV_TILED also a 16-bit copy of the column
  * indices; workgroup size and pass budget follow from the chunk statistics,
- * with SPMV_AUTOTUNE=1 from timed trial launches instead); a no-op for
- * SPMV_WAVE; SPMV_SCALAR and SPMV_WAVE_PIPE share one (see the enum).  A handle belongs to the device that was current when it was
+ * with SPMV_AUTOTUNE=1 from timed trial launches instead); SPMV_SCALAR, SPMV_WAVE
+ * and SPMV_WAVE_PIPE share one (see the enum; a no-op for SPMV_WAVE on rows of mean > 32).  A handle belongs to the device that was current when it was
  * created: plan and run fail with SPMV_ERR_INVALID under another current device.  Excluded from the timed SpMV like the reference
  * excludes its host format build from TIME_KERNEL (e.g. wsp.cu:146 vs :167).
  * A plan snapshots the sparsity PATTERN (row_ptr, col_idx): with borrowed

@@ -388,7 +388,7 @@ int spmv_csr_plan(spmv_csr_t *h, int variant, void *stream)
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
         case SPMV_AUTO: return plan_auto(*h, s);
-        case SPMV_WAVE: return SPMV_OK;
+        case SPMV_WAVE: return h->nnz <= 32 * h->rows ? plan_wave(*h, s) : SPMV_OK;   // short rows: bundles (the long rows' pieces)
         case SPMV_SCALAR:        // (the x windows of the bundle kernel, which SPMV_SCALAR runs with ordered sums)
         case SPMV_WAVE_PIPE: return plan_wave(*h, s);
         case SPMV_VECTOR: return plan_vector(*h, s);
@@ -543,6 +543,9 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
             if (panel.sorted_mode)   // unit bases, block tables, the rows of the tail units, the empty slots of the units in use
                 return panel.units * 4 + (int64_t)panel.nblocks * 20 + panel.tail_units * 512;
             return (int64_t)panel.nblocks * (panel.npanels + 1) * 4 + ((int64_t)panel.nblocks + 1) * 4;
+        case SPMV_WAVE:      // (short rows: the same plan without the windows and the offsets; long rows: none)
+            if (h->nnz > 32 * h->rows) return 0;
+            return (int64_t)h->plan_wave.n_long * 8 + (int64_t)h->plan_wave.pieces * 16;
         case SPMV_SCALAR:    // (the same plan; the ordered kernel does not use the pieces)
         case SPMV_WAVE_PIPE: // the long rows' list, piece table read, partial sums written and re-read (col16 REPLACES 4 of col_idx's bytes with 2)
             return (int64_t)h->plan_wave.n_long * 8 + (int64_t)h->plan_wave.pieces * 16 + h->plan_wave.blocks * 8;
@@ -566,7 +569,8 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
     }
     const ChunkPlan *p = variant == SPMV_ADAPTIVE ? &h->plan_adaptive : (variant == SPMV_TILED ? &h->plan_tiled : nullptr);
     if (variant == SPMV_VECTOR) snprintf(buf, (size_t)n, "lanes_per_row=%d", h->vector_width);
-    else if (variant == SPMV_WAVE_PIPE || variant == SPMV_SCALAR) {
+    else if (variant == SPMV_WAVE && h->nnz > 32 * h->rows) snprintf(buf, (size_t)n, "no plan (a wavefront per row)");
+    else if (variant == SPMV_WAVE_PIPE || variant == SPMV_SCALAR || variant == SPMV_WAVE) {
         if (!h->plan_wave.ready) snprintf(buf, (size_t)n, "not planned (the first run plans)");
         else snprintf(buf, (size_t)n, "long_rows=%d pieces=%d block_rows=%d blocks=%lld blocks_with_x_window=%lld col16=%d", h->plan_wave.n_long,
                       h->plan_wave.pieces, h->plan_wave.block_rows, (long long)h->plan_wave.blocks, (long long)h->plan_wave.win_blocks,

@@ -881,7 +881,12 @@ int launch_wave(spmv_csr &h, const float *x, float *y, bool pipelined, hipStream
     if (!grid_ok(blocks)) return SPMV_ERR_INVALID;
     // bundles of 64 rows pay off while they fit a wave's LDS slice (mean row length <= 32); beyond that a bundle
     // would serialise 64 long rows on one wave (4096 x 4096 at 50 %: 64 waves for the whole chip, 17x slower)
-    const bool bundle = pipelined && h.nnz <= 32 * h.rows;
+    // SPMV_WAVE on short rows (round 4): the same bundles WITHOUT the x window and the 16-bit offsets -- the plain kernel of
+    // the pair (wsp_kernel_v0 beside v1): a wavefront per 64 rows instead of per row (rows of mean 32 left half the lanes of
+    // a wavefront-per-row idle and made every trip one dependent gather), rows longer than a wavefront by the 64-lane
+    // __shfl_down tree, the longest in pieces.  SPMV_WAVE_PIPE adds the window in LDS and the offsets into it.
+    const bool plain_bundle = !pipelined && h.nnz <= 32 * h.rows && getenv("SPMV_WAVE_PER_ROW") == nullptr;
+    const bool bundle = (pipelined && h.nnz <= 32 * h.rows) || plain_bundle;
     if (pipelined && !bundle) {
         hipLaunchKernelGGL(k_wave<true>, dim3((unsigned)blocks), dim3(kBlock), 0, s, h.rows, h.d_row_ptr, h.d_col_idx,
                            h.d_vals, x, y);
@@ -890,7 +895,7 @@ int launch_wave(spmv_csr &h, const float *x, float *y, bool pipelined, hipStream
         const WavePlan &p = h.plan_wave;
         // windows where at least half of the blocks have one (their 35 KiB leave two workgroups per CU); else every
         // gather goes to memory, from three workgroups per CU
-        if (p.windows) launch_bundle<1>(h, p, x, y, p.d_blk_lo, p.d_col16, s);
+        if (p.windows && !plain_bundle) launch_bundle<1>(h, p, x, y, p.d_blk_lo, p.d_col16, s);
         else launch_bundle<0>(h, p, x, y, nullptr, nullptr, s);
 #ifndef SPMV_R_NOLONG
         if (p.n_long) {
