@@ -338,7 +338,10 @@ static int plan_auto(spmv_csr &h, hipStream_t s)
         if ((rc = colsort_probe(h, s, &long_frac, &wide_frac, &lines_est))) return rc;
         // (the estimate of the lines per nonzero prices the layout before it is built: 5 % slack for what it cannot see)
         if (long_frac <= 0.10 && wide_frac <= 0.10 && 0.95 * colsort_cost(4096, lines_est, long_frac) < cost_tiled) {
-            rc = build_panel(h, h.plan_auto_panel, 0, 0, 3, s);
+            // (the layout takes 8192-row blocks where the 4096-row ones touch more than 0.27 lines of x per nonzero: where the
+            // probe's estimate is clearly beyond that, the 4096-row build -- 23 ms at config 4 -- is skipped)
+            const bool big = lines_est > 0.30 && h.rows >= 4096ll * 16 * device_cus(h.device);
+            rc = build_panel(h, h.plan_auto_panel, big ? 8192 : 0, big ? 4 : 0, 3, s);
             if (rc == SPMV_OK) {
                 const PanelPlan &pp = h.plan_auto_panel;
                 const bool fits = (double)pp.tail <= 0.10 * (double)h.nnz && 10 * pp.wide_blocks <= pp.nblocks;

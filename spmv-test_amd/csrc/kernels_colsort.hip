@@ -130,6 +130,36 @@ __device__ __forceinline__ int wave_scan_lds(int *a, int count, int lane, int *n
     return carry;
 }
 
+// The widest block: max over the blocks of (largest - smallest column) of ALL their nonzeros, for sizing the counters of step 1
+__global__ __launch_bounds__(kBlock) void k_cb_span(const int32_t *__restrict__ brow, const int32_t *__restrict__ row_ptr,
+                                                    const int32_t *__restrict__ col_idx, int32_t *__restrict__ widest)
+{
+    __shared__ int s_mn[kBlock / kWave], s_mx[kBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+    const int s = row_ptr[brow[blockIdx.x]], e = row_ptr[brow[blockIdx.x + 1]];
+    int mn = INT_MAX, mx = -1;
+    for (int k = s + tid; k < e; k += kBlock) {
+        const int c = col_idx[k];
+        mn = c < mn ? c : mn;
+        mx = c > mx ? c : mx;
+    }
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int a = __shfl_xor(mn, o, kWave), c = __shfl_xor(mx, o, kWave);
+        mn = a < mn ? a : mn;
+        mx = c > mx ? c : mx;
+    }
+    if (lane == 0) { s_mn[wv] = mn; s_mx[wv] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kBlock / kWave; ++w) {
+            mn = s_mn[w] < mn ? s_mn[w] : mn;
+            mx = s_mx[w] > mx ? s_mx[w] : mx;
+        }
+        if (mx >= mn) atomicMax(widest, mx - mn);
+    }
+}
+
 // Step 1, one workgroup per block: t_* (CSR index space: block b fills [row_ptr[brow[b]], ...)) =
 //   [ the nonzeros of its short rows, stably sorted by line of x | the nonzeros of its long rows in CSR order ]
 // (bins of 2^shift columns, shift = 5 unless the block spans more than 32768 lines), nshort[b] = where the second part
@@ -139,9 +169,12 @@ __global__ __launch_bounds__(kBlock) void k_cb_sort(const int32_t *__restrict__ 
                                                     const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
                                                     const uint16_t *__restrict__ rowloc, int32_t *__restrict__ t_col,
                                                     uint16_t *__restrict__ t_row, float *__restrict__ t_val,
-                                                    int32_t *__restrict__ nshort, unsigned long long *__restrict__ stats)
+                                                    int32_t *__restrict__ nshort, unsigned long long *__restrict__ stats, int nbins)
 {
-    extern __shared__ int hist[];   // kCbBins
+    // nbins counters (a power of two, at most kCbBins): as many as the widest block needs at 32 columns per bin -- a band of
+    // 200 000 columns: 8192 counters, 32 KiB, four workgroups per CU where 128 KiB allowed one (the scatter below runs on ONE
+    // wavefront per block: round 3's 25 ms of plan time at config 4 were 256 wavefronts on the whole chip)
+    extern __shared__ int hist[];   // nbins
     __shared__ unsigned longmask[kCbRowsMax / 32];
     __shared__ int uniq[1024];
     __shared__ int s_mn[kBlock / kWave], s_mx[kBlock / kWave];
@@ -156,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_cb_sort(const int32_t *__restrict__ 
     // ---- all four wavefronts: long rows, column range, histogram (the passes that are only reads)
     const int lmax = long_row_limit(e - s);
     for (int i = tid; i < kCbRowsMax / 32; i += kBlock) longmask[i] = 0u;
-    for (int i = tid; i < kCbBins; i += kBlock) hist[i] = 0;
+    for (int i = tid; i < nbins; i += kBlock) hist[i] = 0;
     __syncthreads();
     for (int i = tid; i < nrows; i += kBlock)
         if (row_ptr[row0 + i + 1] - row_ptr[row0 + i] > lmax) atomicOr(&longmask[i >> 5], 1u << (i & 31));
@@ -183,13 +216,13 @@ __global__ __launch_bounds__(kBlock) void k_cb_sort(const int32_t *__restrict__ 
     }
     if (mx < 0) mn = 0;   // no short row at all
     int shift = 5;
-    while (mx >= 0 && ((mx - mn) >> shift) >= kCbBins) ++shift;
+    while (mx >= 0 && ((mx - mn) >> shift) >= nbins) ++shift;
     for (int k = s + tid; k < e; k += kBlock)
         if (!is_long(rowloc[k])) atomicAdd(&hist[(col_idx[k] - mn) >> shift], 1);
     __syncthreads();
     if (wv != 0) return;   // ---- the rest is sequential in the bins' cursors: one wavefront
     int used = 0;
-    const int ns = wave_scan_lds(hist, kCbBins, lane, &used);
+    const int ns = wave_scan_lds(hist, nbins, lane, &used);
     if (lane == 0) {
         nshort[b] = ns;
         atomicAdd(&stats[0], (unsigned long long)(shift == 5 ? used : ns));
@@ -762,11 +795,20 @@ static int build_colsort(spmv_csr &h, PanelPlan &p, int rows_cap, hipStream_t s)
     SPMV_HIP_TRY(hipMemsetAsync(o_row.p, 0xFF, sizeof(uint16_t) * slots, s));
     if (h.nnz > 0) {
         if ((rc = panel_rowloc(h, brow.p, p.nblocks, rowloc.p, s))) return rc;
-        const size_t lds = sizeof(int) * (size_t)kCbBins;
+        // counters for the widest block at 32 columns each (wider blocks than kCbBins counters reach use coarser bins)
+        int32_t widest = 0;
+        SPMV_HIP_TRY(hipMemsetAsync(total.p, 0, sizeof(int32_t), s));
+        k_cb_span<<<dim3((unsigned)p.nblocks), dim3(kBlock), 0, s>>>(brow.p, h.d_row_ptr, h.d_col_idx, total.p);
+        if ((rc = check_launch("k_cb_span"))) return rc;
+        SPMV_HIP_TRY(hipMemcpyAsync(&widest, total.p, sizeof widest, hipMemcpyDeviceToHost, s));
+        SPMV_HIP_TRY(hipStreamSynchronize(s));
+        int nbins = 1024;
+        while (nbins < kCbBins && (widest >> 5) >= nbins) nbins <<= 1;
+        const size_t lds = sizeof(int) * (size_t)nbins;
         static LdsOptIn optin;
-        if ((rc = optin.ensure(reinterpret_cast<const void *>(&k_cb_sort), h.device, (int)lds))) return rc;
+        if ((rc = optin.ensure(reinterpret_cast<const void *>(&k_cb_sort), h.device, (int)(sizeof(int) * (size_t)kCbBins)))) return rc;
         k_cb_sort<<<dim3((unsigned)p.nblocks), dim3(kBlock), lds, s>>>(brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p,
-                                                                        t_col.p, t_row.p, t_val.p, nshort.p, stats.p);
+                                                                        t_col.p, t_row.p, t_val.p, nshort.p, stats.p, nbins);
         if ((rc = check_launch("k_cb_sort"))) return rc;
         k_cb_groups<<<dim3((unsigned)p.nblocks), dim3(kWave), 0, s>>>(brow.p, h.d_row_ptr, ubeg.p, nshort.p, t_col.p, t_row.p,
                                                                        t_val.p, reinterpret_cast<int32_t *>(packed.p), o_row.p,

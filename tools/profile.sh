@@ -14,11 +14,11 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 5 --no-extras --no-cpu-baseline $EXTRA"
+ARGS="--steps 50 --warmup 5 --no-extras --no-cpu-baseline --traffic off $EXTRA"
 # pass 1 keeps the CPU baseline when no extra arguments are given, so that the committed bench line
 # (profiles/<tag>_bench_n1.json) and the kernel statistics come from ONE process (one plan, one device); the other
 # workloads stay out of it -- their launches of the same kernels would blur the per-kernel averages
-if [ -z "$EXTRA" ]; then TRACE_ARGS="--steps 50 --warmup 5 --no-extras"; else TRACE_ARGS="$ARGS"; fi
+if [ -z "$EXTRA" ]; then TRACE_ARGS="--steps 50 --warmup 5 --no-extras --traffic off"; else TRACE_ARGS="$ARGS"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $TRACE_ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err

@@ -6,8 +6,14 @@ Writes  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summa
                                           the calibration on a pure 16-B/lane stream of known size
         profiles/traffic.json             HBM bytes per launch of the dominant kernel, read by bench.py
 Correction (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the
-128-B requests of a wide coalesced read at 64 B, i.e. reports exactly half the bytes -> read bytes =
-2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.  The calibration section re-measures that factor here."""
+128-B requests of a wide coalesced read at 64 B, i.e. reports exactly half the bytes; WRITE_SIZE is exact.  The
+calibration passes re-measure both factors on a pure 16-B/lane stream of known size and the summary applies what THEY
+gave.  Access classes (round 4, profiles/r04_calibration.json, tools/calib_counters.py): a 4-byte gather that misses every
+cache is ONE request for the whole 128-byte line, tallied 64 bytes like a stream's request (touching both halves of the line
+costs no second request) -- so the stream factor is right for the gather kernels (k_panel, k_colsort) as well; what their
+counters show above the HBM rate is traffic the 256 MiB Infinity Cache serves, which FETCH_SIZE counts too.
+(bench.py measures the same two counters itself since round 4 -- child passes cut at marker dispatches, the calibration
+kernels of csrc/kernels_calib.hip in the same passes; this script is the stand-alone route for a single workload.)"""
 import csv
 import glob
 import json
@@ -64,22 +70,29 @@ def main():
         f_kib, n = fetch[k]
         w_kib = write.get(k, (0.0, 0))[0]
         kernels[k] = {"launches": n, "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
-                      "hbm_bytes_per_launch": int(round((2 * f_kib + w_kib) * 1024))}
+                      "hbm_bytes_per_launch": int(round((read_factor * f_kib + write_factor * w_kib) * 1024))}
     # the plan autotunes over several instantiations of k_adaptive: the timed one has the most launches
-    hot = (("k_panel(", "k_colsort") if variant == "panel" else
-           ("k_wave_bundle",) if variant in ("wave_pipe", "scalar") else
+    binned = variant == "panel" and "binned" in plan
+    hot = (("k_bin_products",) if binned else ("k_panel(", "k_colsort") if variant == "panel" else
+           ("k_wave_bundle",) if variant in ("wave_pipe", "scalar", "wave") else
            ("k_adaptive", "k_tiled16", "k_tiled_mixed", "k_sorted"))
     dom = max((k for k in kernels if any(h in k for h in hot)), key=lambda k: kernels[k]["launches"])
-    if variant == "wave_pipe":      # one SpMV = bundles + pieces + combine: the counters of all three
+    if variant in ("wave_pipe", "wave"):      # one SpMV = bundles + pieces + combine: the counters of all three
         for k in kernels:
             if k != dom and ("k_wave_pieces" in k or "k_wave_combine" in k):
                 for key in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_per_launch"):
                     kernels[dom][key] = kernels[dom][key] + kernels[k][key]
         kernels[dom]["note"] = "counters of k_wave_bundle + k_wave_pieces + k_wave_combine: one SpMV"
+    if binned:                      # one SpMV = the product launch + the sum launch
+        for k in kernels:
+            if k != dom and "k_bin_sums" in k:
+                for key in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_per_launch"):
+                    kernels[dom][key] = kernels[dom][key] + kernels[k][key]
+        kernels[dom]["note"] = "counters of k_bin_products + k_bin_sums: one SpMV"
     # the panel sweep covers the matrix in several launches of the same kernel ("launches=N" in the plan string):
     # scale the per-launch counters to one SpMV so they compare with the algorithmic bytes of one SpMV
     per_spmv = 1
-    if variant == "panel" and "launches=" in bench.get("plan", ""):
+    if variant == "panel" and not binned and "launches=" in bench.get("plan", ""):
         per_spmv = int(bench["plan"].split("launches=")[1].split()[0])
     if per_spmv > 1:
         for key in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_per_launch"):
