@@ -314,13 +314,16 @@ __global__ __launch_bounds__(kSumWaves *kWave) void k_bin_sums(int nb, int np, c
                 }
             }
         };
+        // two register sets, both in flight at the top of the loop: a set is summed, then re-issued at once (its registers
+        // are free), while the other set's loads are still out -- the waits inside consume() count the younger set's loads
         Set sa, sb;
         issue(0, sa);
-        for (int ci0 = 0; ci0 < total; ci0 += 2 * kD) {             // two register sets: one in flight while the other is summed
-            issue(ci0 + kD, sb);
+        issue(kD, sb);
+        for (int ci0 = 0; ci0 < total; ci0 += 2 * kD) {
             consume(sa);
             issue(ci0 + 2 * kD, sa);
             consume(sb);
+            issue(ci0 + 3 * kD, sb);
         }
     }
     // the long rows of the bin: their spare sums join the row's own, in slot order
