@@ -284,6 +284,48 @@ def traffic_child(args):
     Path(args.traffic_child).write_text(json.dumps(manifest))
 
 
+PROBE = ROOT / "spmv-test_amd" / "bin" / "spmv_traffic_probe"
+
+
+def write_probe_job(args, W, variant_id, world, device, tmp):
+    """The job file of bin/spmv_traffic_probe (host/traffic_probe.cpp) for the workloads of this line: row pointers (numpy,
+    this process: no GPU needed) as raw files, everything else as numbers.  Returns [(id, key, label)]."""
+    lines = [f"V {variant_id} {TRAFFIC_RUNS} {device}"]
+    listed = []
+
+    def synth(ident, w, row0, n_loc):
+        f = tmp / f"rp_{ident}_{row0}.bin"
+        W.row_ptr(w, row0, n_loc).tofile(f)
+        lines.append(f"W {ident} {w.seed} {row0} {n_loc} {w.rows} {w.cols} {w.band} {f}")
+    if world > 1 or args.scaling == "strong":
+        w, sub_rows, S, owned = rank_blocks(args, W, world, 0)
+        for b in owned:
+            synth(0, w, b * sub_rows, sub_rows)
+        listed.append((0, "rank", w.describe()))
+    else:
+        todo = [(args.config, args.band)] + ([] if args.no_extras else extra_list(args))
+        for ident, (cname, band) in enumerate(todo):
+            if cname == "stencil7":
+                n3, rp, ci, va = W.stencil7(200)
+                files = []
+                for nm, a in (("rp", rp), ("ci", ci), ("va", va)):
+                    f = tmp / f"st_{nm}_{ident}.bin"
+                    a.tofile(f)
+                    files.append(str(f))
+                lines.append(f"F {ident} {n3} {n3} {len(ci)} " + " ".join(files))
+                listed.append((ident, wkey(cname, band), "stencil7"))
+                continue
+            if cname in ("c5", "c5shard"):
+                w, n_loc = W.c5(8, band=band), 16 << 20
+            else:
+                w = W.config(cname, band=band)
+                n_loc = w.rows
+            synth(ident, w, 0, n_loc)
+            listed.append((ident, wkey(cname, band), w.describe()))
+    (tmp / "job.txt").write_text("\n".join(lines) + "\n")
+    return listed
+
+
 def cut_counter_file(directory, counter):
     """{marker id: {"kib": sum of Counter_Value, "kernels": {name: kib}, "dispatches": n}} of the newest counter file."""
     files = sorted(glob.glob(str(Path(directory) / "**" / "*_counter_collection.csv"), recursive=True),
@@ -329,12 +371,22 @@ def measure_traffic(args, world=1, device=0):
         env.pop(k, None)
     segs, manifest = {}, None
     try:
+        listed = None
+        if PROBE.exists() and os.environ.get("SPMV_BENCH_TRAFFIC_CHILD", "native") == "native":
+            # the native child (no Python, no torch under the profiler): its job = the workloads as numbers + row-pointer files
+            W = ge.load_package().workloads
+            vid = {"scalar": 0, "wave": 1, "wave_pipe": 2, "vector": 3, "adaptive": 4, "tiled": 5, "panel": 6, "auto": 7}[args.variant]
+            listed = write_probe_job(args, W, vid, world, device, tmp)
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = tmp / counter.lower()
             man = tmp / f"manifest_{counter}.json"
             # the program itself directly after `--` (no env/bash hop: the profiler's preloaded library initialises the GPU)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", str(out), "--", sys.executable, str(ROOT / "bench.py"),
-                   "--traffic-child", str(man)] + fwd
+            if listed is not None:
+                cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", str(out), "--", str(PROBE), str(tmp / "job.txt"),
+                       str(tmp / f"plans_{counter}.txt")]
+            else:
+                cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", str(out), "--", sys.executable, str(ROOT / "bench.py"),
+                       "--traffic-child", str(man)] + fwd
             log = open(tmp / f"{counter}.log", "w")
             p = subprocess.Popen(cmd, cwd=str(tmp), env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
             try:
@@ -345,11 +397,16 @@ def measure_traffic(args, world=1, device=0):
                 return None, f"not measured: the counter passes exceeded their {args.traffic_timeout:.0f} s (stopped in the {counter} pass)"
             finally:
                 log.close()
-            if rc != 0 or not man.exists():
+            if listed is not None and rc == 0 and (tmp / f"plans_{counter}.txt").exists():
+                plans = dict(l.split("\t", 1) for l in (tmp / f"plans_{counter}.txt").read_text().splitlines() if "\t" in l)
+                manifest = {"runs": TRAFFIC_RUNS, "child": "bin/spmv_traffic_probe",
+                            "workloads": [{"id": i, "key": k, "label": lab, "plan": plans.get(str(i), "?")} for i, k, lab in listed]}
+            elif rc != 0 or not man.exists():
                 tail = (tmp / f"{counter}.log").read_text(errors="replace")[-300:].replace("\n", " | ")
                 return None, f"not measured: rocprofv3 --pmc {counter} child rc={rc}: {tail}"
+            else:
+                manifest = json.loads(man.read_text())
             segs[counter] = cut_counter_file(out, counter)
-            manifest = json.loads(man.read_text())
         runs = manifest["runs"]
         fseg, wseg = segs["FETCH_SIZE"], segs["WRITE_SIZE"]
 
@@ -389,8 +446,10 @@ def measure_traffic(args, world=1, device=0):
                                                               + write_factor * per_run(wseg, 100 + i) * runs))}
         res = {"calibration": cal, "workloads": wl, "seconds": round(time.perf_counter() - t0, 1),
                "child_seconds": manifest.get("seconds")}
-        return res, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this file "
-                     f"(--traffic-child, {runs} launches per workload behind marker dispatches), corrected with the factors the "
+        who = ("bin/spmv_traffic_probe (the workloads of this line through libspmv_hip.so, no Python under the profiler)"
+               if listed is not None else "this file (--traffic-child)")
+        return res, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of {who}, "
+                     f"{runs} launches per workload behind marker dispatches, corrected with the factors the "
                      "spmv_calib_* kernels gave in the same passes")
     except Exception as ex:                       # a measurement aid must never cost the line
         return None, f"not measured: {type(ex).__name__}: {str(ex)[:200]}"

@@ -123,6 +123,33 @@ def test_all_variants_agree_on_every_row(c4, pkg):
         assert bad == 0, f"{name}: {bad} rows differ from scalar beyond {RTOL}*sum|terms|"
 
 
+def test_binned_layout_forced_at_full_size(c4, pkg):
+    """The binned layout of the panel family (round 4) forced on the uniform-column fixtures -- config 4 (512 panels, 83
+    nonzeros per tile: what SPMV_AUTO takes) and config 5's shards (4096 panels of 32768 columns = the layout's limit, ten
+    nonzeros per tile: where AUTO keeps the sweep) -- against SCALAR (bit-identical to the oracle wherever sampled) on every
+    row, and again on a second handle planned with the reported numbers (bit-identical)."""
+    import torch
+    if c4["w"].band != 0:
+        pytest.skip("uniform columns only (the banded fixtures' tiles are a few fat ones per bin: covered at small scale)")
+    capi = pkg.capi
+    ref = _run(c4, pkg, capi.SCALAR)
+    B = capi.CsrMatrix.from_device(c4["n"], c4["w"].cols, c4["d_rp"], c4["d_ci"], c4["d_va"])
+    B.plan_set(capi.PANEL, [capi.PANEL, 0, 0, 0, 0, 0, 4, 0])
+    d = B.plan_describe(capi.PANEL)
+    assert d.startswith("binned bins=") and "flagged_tiles=0 " in d, d
+    y = torch.full((c4["n"],), float("nan"), device=c4["d_x"].device)
+    B.run(capi.PANEL, c4["d_x"], y)
+    torch.cuda.synchronize()
+    assert not torch.isnan(y).any()
+    bad = ((y - ref).abs() > RTOL * c4["mag"] + 1e-37).sum().item()
+    assert bad == 0, f"binned: {bad} rows differ from scalar beyond {RTOL}*sum|terms|"
+    y2 = torch.full((c4["n"],), float("nan"), device=c4["d_x"].device)
+    B.run(capi.PANEL, c4["d_x"], y2)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    B.close()
+
+
 def test_auto_choice_at_full_size(c4, pkg):
     """SPMV_AUTO at the BASELINE sizes: the LDS-tiled kernel on a band of 8192 columns; on uniform columns the binned layout
     of the panel family (round 4: two streaming launches) where a (bin, panel) tile still holds dozens of nonzeros -- config
