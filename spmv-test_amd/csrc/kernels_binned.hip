@@ -235,7 +235,8 @@ __global__ __launch_bounds__(kSumWaves *kWave) void k_bin_sums(int nb, int np, c
                                                                const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ pm,
                                                                const uint16_t *__restrict__ r16, const float *__restrict__ prod,
                                                                const int32_t *__restrict__ lptr, const uint32_t *__restrict__ lrow,
-                                                               const int32_t *__restrict__ lcnt, float *__restrict__ y)
+                                                               const int32_t *__restrict__ lcnt, float *__restrict__ y,
+                                                               uint32_t prod_bytes, uint32_t r16_bytes)
 {
     constexpr int kPiece = kWave * E, kShift = E == 4 ? 8 : 7, kD = E == 4 ? 4 : 8;   // pieces per register set
     constexpr int kStride = RB + kSpare + kWave;                    // a wave's sums, the spare sums of its long rows, the dummy word
@@ -250,8 +251,9 @@ __global__ __launch_bounds__(kSumWaves *kWave) void k_bin_sums(int nb, int np, c
     for (int i = lane; i < kDummy; i += kWave) sums[i] = 0.0f;
     const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
     const int32_t *qp = pm + (int64_t)b * np;
-    typedef float fEu __attribute__((ext_vector_type(E), aligned(4)));
-    struct Set { fEu v[kD]; int r[kD][E]; int left[kD]; int q[kD], s[kD]; };
+    struct Set { float v[kD][E]; int r[kD][E]; int left[kD]; int q[kD], s[kD]; };
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(prod), 0, (int)prod_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(r16), 0, (int)r16_bytes, 0x00020000);
     for (int tb = 0; tb < np; tb += kWave) {                        // 64 tiles of the bin: a lane holds one tile's three numbers
         const int t = tb + lane;
         int s_l = 0, n_l = 0, q_l = 0;
@@ -284,11 +286,27 @@ __global__ __launch_bounds__(kSumWaves *kWave) void k_bin_sums(int nb, int np, c
                 c.left[u] = live ? n - off : 0;
                 c.q[u] = q + off;                                   // (bit 31 of q: the tile is flagged)
                 c.s[u] = s + off;
-                const int at = off + E * lane;
-                c.v[u] = *reinterpret_cast<const fEu *>(prod + (q & 0x7fffffff) + at);
-                const uint16_t *rp = r16 + s + at;
-#pragma unroll
-                for (int k = 0; k < E; ++k) c.r[u][k] = rp[k];
+                // buffer loads: the piece's position is the SCALAR offset, the lane's share a constant vector offset -- no
+                // address arithmetic per piece on the vector side (reads past the arrays' ends return 0)
+                const unsigned qb = (unsigned)((q & 0x7fffffff) + off) * 4u, sb = (unsigned)(s + off) * 2u;
+                if (E == 4) {
+                    const auto pv = __builtin_amdgcn_raw_buffer_load_b128(pr, lane * 16, (int)qb, 0);
+                    c.v[u][0] = __uint_as_float(pv[0]); c.v[u][1] = __uint_as_float(pv[1]);
+                    c.v[u][2] = __uint_as_float(pv[2]); c.v[u][3] = __uint_as_float(pv[3]);
+                } else {
+                    const auto pv = __builtin_amdgcn_raw_buffer_load_b64(pr, lane * 8, (int)qb, 0);
+                    c.v[u][0] = __uint_as_float(pv[0]); c.v[u][1] = __uint_as_float(pv[1]);
+                }
+                // (the rows of a lane: one load; a tile starts at any entry, so the address is 2-byte aligned only -- the
+                // memory pipeline takes that, as it does for the global loads the compiler makes of a uint16_t pointer)
+                if (E == 4) {
+                    const auto rv = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, (int)sb, 0);
+                    c.r[u][0] = (int)(rv[0] & 0xffffu); c.r[u][1] = (int)(rv[0] >> 16);
+                    c.r[u][2] = (int)(rv[1] & 0xffffu); c.r[u][3] = (int)(rv[1] >> 16);
+                } else {
+                    const unsigned rv = __builtin_amdgcn_raw_buffer_load_b32(rr, lane * 4, (int)sb, 0);
+                    c.r[u][0] = (int)(rv & 0xffffu); c.r[u][1] = (int)(rv >> 16);
+                }
             }
         };
         auto consume = [&](Set &c) {
@@ -485,8 +503,8 @@ int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s)
         return SPMV_ERR_INVALID;
     }
     const int np = np64 < 1 ? 1 : (int)np64;
-    if (h.nnz > (int64_t)INT_MAX - 8ll * np - 64) {
-        set_error("spmv_csr_plan(panel, binned): nnz %lld too close to 2^31 for one handle", (long long)h.nnz);
+    if (h.nnz > (1ll << 30) - 8ll * np - 512) {     // (the products are addressed through a buffer descriptor: 4 GiB)
+        set_error("spmv_csr_plan(panel, binned): nnz %lld beyond the layout's 2^30 nonzeros per handle", (long long)h.nnz);
         return SPMV_ERR_INVALID;
     }
     const int cus = device_cus(h.device);
@@ -611,7 +629,7 @@ static int launch_sums_e(const spmv_csr &h, const PanelPlan &p, float *y, hipStr
     static LdsOptIn optin;
     if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_bin_sums<RB, E>), h.device, (int)lds)) return rc;
     k_bin_sums<RB, E><<<grid, block, lds, s>>>(p.nblocks, p.npanels, p.d_brow, p.d_tile_ptr, p.d_pm, p.d_r16, p.d_prod, p.d_lptr,
-                                               p.d_lrow, p.d_lcnt, y);
+                                               p.d_lrow, p.d_lcnt, y, (uint32_t)((p.padded + 264) * 4), (uint32_t)((h.nnz + 264) * 2));
     return check("k_bin_sums");
 }
 template <int RB>
