@@ -320,3 +320,40 @@ def test_column_range(pkg, gpu):
     prob = DeviceProblem(pkg, gpu, 2, 20, np.zeros(3, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), np.ones(20, np.float32))
     assert prob.A.column_range() == (20, -1)
     prob.A.close()
+
+
+def test_calibration_kernels_and_marker(pkg, gpu):
+    """The measurement aids of include/spmv_hip.h (spmv_calib_*): they run on buffers of the sizes they are told, refuse the
+    arguments they cannot take, and the cold first-launch time of a *_run_host call is on record beside the warm one."""
+    import torch
+    capi = pkg.capi
+    table = torch.zeros(1 << 22, dtype=torch.float32, device=gpu)          # 16 MiB = 2^17 lines
+    sink = torch.zeros(16, dtype=torch.float32, device=gpu)
+    capi.calib_marker(7)
+    capi.calib_stream(table, table.numel() * 4, sink)
+    for touch in (1, 2, 4):
+        capi.calib_gather(table, 1 << 17, 1 << 17, touch, sink)
+    capi.calib_store(table, 1 << 20, 4)
+    capi.calib_store(table, 1 << 20, 16)
+    torch.cuda.synchronize()
+    assert float(sink.sum()) == 0.0                                          # the sink is never written
+    assert float(table[: (1 << 20) // 4].min()) == 1.0 and float(table[(1 << 20) // 4:].max()) == 0.0
+    for bad in (lambda: capi.calib_marker(0), lambda: capi.calib_marker(70000),
+                lambda: capi.calib_stream(table, 24, sink),                  # not a multiple of 16
+                lambda: capi.calib_gather(table, 3 << 10, 16, 1, sink),      # lines not a power of two
+                lambda: capi.calib_gather(table, 1 << 10, 1 << 11, 1, sink),  # more lines than the table has
+                lambda: capi.calib_gather(table, 1 << 10, 16, 3, sink),
+                lambda: capi.calib_store(table, 1 << 20, 8)):
+        with pytest.raises(capi.SpmvError) as e:
+            bad()
+        assert e.value.status == capi.ERR_INVALID
+    # the launchers' figure: first (cold) launch kept beside the warm one
+    rp = np.arange(0, 4097, dtype=np.int32) * 8
+    ci = (np.arange(4096 * 8, dtype=np.int32) * 7) % 4096
+    va = np.ones(4096 * 8, np.float32)
+    A = capi.CsrMatrix.from_host(4096, 4096, rp, ci, va)
+    y = np.empty(4096, np.float32)
+    warm = A.run_host(capi.ADAPTIVE, np.ones(4096, np.float32), y)
+    cold = capi.lib().spmv_last_first_launch_ms()
+    assert warm > 0 and cold > 0 and np.all(y == 8.0)
+    A.close()
