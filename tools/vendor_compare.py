@@ -112,13 +112,39 @@ def rocsparse_times(rs, rows, cols, nnz, d_rp, d_ci, d_va, d_x, d_y, iters=20, a
     return out
 
 
+def warm():
+    """--warm: load librocsparse.so and run its two algorithms once on a tiny matrix, in a process of its own -- what that
+    touches of the 0.5 GB file (the relocations, the gfx950 code objects) is then in the page cache when bench.py loads the
+    library itself.  (Reading the whole file -- every architecture's code -- took a freshly booted box more than four minutes.)"""
+    import numpy as np
+    import torch
+    dev = torch.device("cuda:0")
+    rs = RocSparse()
+    rs._ok(rs.L.rocsparse_set_stream(rs.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "set_stream")
+    n, k = 4096, 8
+    d_rp = torch.arange(0, n * k + 1, k, dtype=torch.int32, device=dev)
+    d_ci = torch.from_numpy((np.arange(n * k, dtype=np.int64) * 7 % n).astype(np.int32)).to(dev)
+    d_va = torch.ones(n * k, dtype=torch.float32, device=dev)
+    d_x = torch.ones(n, dtype=torch.float32, device=dev)
+    d_y = torch.zeros(n, dtype=torch.float32, device=dev)
+    rt = rocsparse_times(rs, n, n, n * k, d_rp, d_ci, d_va, d_x, d_y, iters=1,
+                         algs={a: ALGS[a] for a in ("csr_adaptive", "csr_nnzsplit")})
+    torch.cuda.synchronize()
+    print(json.dumps({"warmed": sorted(rt), "y_ok": bool((d_y == k).all().item())}))
+    rs.close()
+
+
 def main():
     import torch
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--warm", action="store_true", help="only load the library and run it once on a tiny matrix (bench.py's warm-up child)")
     args = ap.parse_args()
+    if args.warm:
+        warm()
+        return
 
     pkg = ge.load_package()
     capi, W = pkg.capi, pkg.workloads
