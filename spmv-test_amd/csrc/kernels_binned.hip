@@ -106,11 +106,11 @@ __global__ __launch_bounds__(256) void k_bin_fill(int nb, int np, const int32_t 
                                                   const int32_t *__restrict__ pm, uint16_t *__restrict__ c16, float *__restrict__ pvals,
                                                   uint16_t *__restrict__ r16)
 {
-    __shared__ int cursor_all[4][kMaxPanels];
+    extern __shared__ int cursor_all[];     // 4 x np: as many workgroups per CU as the panel count allows (a wave walks its bin alone)
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + w;
     if (b >= nb) return;
-    int *cursor = cursor_all[w];
+    int *cursor = cursor_all + w * np;
     const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
     const int32_t *qp = pm + (int64_t)b * np;
     for (int p = lane; p < np; p += kWave) cursor[p] = tp[p];
@@ -562,8 +562,8 @@ int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s)
     SPMV_HIP_TRY(hipMemsetAsync(pvals.p, 0, sizeof(float) * nslot, s));
     if (h.nnz > 0) {
         if ((rc = panel_rowloc(h, brow.p, nb, rowloc.p, s))) return rc;
-        k_bin_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s>>>(nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p,
-                                                                        tiles.p, pm.p, c16.p, pvals.p, r16.p);
+        k_bin_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), sizeof(int) * 4 * (size_t)np, s>>>(
+            nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, tiles.p, pm.p, c16.p, pvals.p, r16.p);
         if ((rc = check("k_bin_fill"))) return rc;
     }
     // the product launch: every panel's stream shared by `splits` workgroups so that the launch is at least two rounds of CUs
