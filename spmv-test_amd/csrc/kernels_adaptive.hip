@@ -832,8 +832,15 @@ __device__ __forceinline__ void sorted_body(float *smem, ChunkShared<BLOCK> &sh,
     {
         const u4 *p4 = reinterpret_cast<const u4 *>(perm + (int64_t)ci * kChunkT);
         const f4 *v4 = reinterpret_cast<const f4 *>(vals + base);
+#ifdef SPMV_SORTED_FAKE7      // A/B build (wrong y): three quarters of the words' bytes are read -- what a 3-byte word would stream
+#pragma unroll
+        for (int j = 0; j < kVec - 1; ++j) pw[j] = __builtin_nontemporal_load(&p4[j * BLOCK + tid]);
+        // (the fourth vector made up from the third: other positions, other lines of x -- the gathers and the LDS scatter keep their work)
+        for (int q = 0; q < 4; ++q) pw[kVec - 1][q] = (pw[kVec - 2][q] ^ (1u << kColBits)) + 37u;
+#else
 #pragma unroll
         for (int j = 0; j < kVec; ++j) pw[j] = __builtin_nontemporal_load(&p4[j * BLOCK + tid]);
+#endif
 #pragma unroll
         for (int j = 0; j < kVec; ++j) vv[j] = __builtin_nontemporal_load(&v4[j * BLOCK + tid]);
     }
