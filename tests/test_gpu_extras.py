@@ -35,6 +35,27 @@ def test_run_is_graph_capturable(pkg, oracle, gpu):
             g.replay()
         torch.cuda.synchronize()
         assert_close_to_oracle(prob.d_y[:w.rows].cpu().numpy(), y64, mag, f"graph/{name}")
+    # the panel family too: the sweep, the sorted blocks and the binned layout (two launches + the scratch products) through
+    # spmv_csr_plan_set, and SPMV_WAVE on short rows (the bundles and the long rows' pieces: three launches)
+    for name, params in (("panel sweep", [pkg.capi.PANEL, 0, 0, 0, 0, 0, 1, 0]), ("sorted blocks", [pkg.capi.PANEL, 0, 0, 0, 0, 0, 3, 0]),
+                         ("binned", [pkg.capi.PANEL, 0, 0, 0, 0, 0, 4, 0]), ("wave", None)):
+        v = pkg.capi.PANEL if params else pkg.capi.WAVE
+        if params:
+            prob.A.plan_set(v, params)
+        else:
+            prob.A.plan(v)
+        prob.A.run(v, prob.d_x, prob.d_y)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                prob.A.run(v, prob.d_x, prob.d_y, stream=s)
+        prob.d_y.fill_(float("nan"))
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert_close_to_oracle(prob.d_y[:w.rows].cpu().numpy(), y64, mag, f"graph/{name}")
 
 
 def test_tiled_plan_picks_workgroup_size_from_the_data(pkg, oracle, gpu):
