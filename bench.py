@@ -651,7 +651,7 @@ def dominant_kernel(resolved, plan_now):
     def _n(key):
         return int(plan_now.split(key + "=")[1].split()[0]) if key + "=" in plan_now else 0
     if resolved == "panel":
-        return "k_bin_products + k_bin_sums" if "binned" in plan_now else "k_colsort" if "sorted_blocks=" in plan_now else "k_panel"
+        return "k_bs_products + k_bs_sums" if "scattered_products" in plan_now else "k_bin_products + k_bin_sums" if "binned" in plan_now else "k_colsort" if "sorted_blocks=" in plan_now else "k_panel"
     if resolved == "tiled" and (_n("col16_chunks") or _n("sorted_chunks")):
         # one launch: all chunks 16-bit -> k_tiled16, all sorted -> k_sorted, otherwise the three bodies in k_tiled_mixed
         return ("k_tiled16" if _n("col16_chunks") == _n("chunks") else

@@ -361,10 +361,15 @@ static int plan_auto(spmv_csr &h, hipStream_t s)
         // two of products: the binned layout -- two streaming launches, nothing gathered from memory
         // (measured, profiles/r04_binned_*.jsonl: config 4 uniform 1.33 -> 1.06 ms at 83 nonzeros per tile, config 3 uniform
         // 0.86 -> 0.52 ms at 663; config 5's shard 3.0 -> 4.1 ms at 10: below ~48 the sum launch works on quarter-empty pieces)
-        bool try_binned = h.cols * (int64_t)sizeof(float) >= (8ll << 20) && binned_tile_nonzeros(h, 4096) >= 48.0;
-        if (const char *e = getenv("SPMV_AUTO_BINNED")) try_binned = try_binned && atoi(e) != 0;   // 0: never (A/B runs)
+        // Thinner tiles (config 5's shard: 14 at 4096 rows per bin, 28 at 8192): the flavour whose product launch stores in bin
+        // order -- the sum launch then streams whatever the tiles hold (3.0 -> 1.55 ms there, the sweep with its shorter step 2.4;
+        // at config 4 it reads 1.24 ms against 1.04: the destinations are 4 more bytes per nonzero and the stores come in runs)
+        const bool big_x = h.cols * (int64_t)sizeof(float) >= (8ll << 20);
+        const double tile = binned_tile_nonzeros(h, 4096);
+        int try_binned = big_x && tile >= 48.0 ? 4 : big_x && 2.0 * tile >= 8.0 ? 5 : 0;
+        if (const char *e = getenv("SPMV_AUTO_BINNED")) try_binned = atoi(e) != 0 ? try_binned : 0;   // 0: never (A/B runs)
         if (try_binned) {
-            rc = build_panel(h, h.plan_auto_panel, 0, 0, 4, s);
+            rc = build_panel(h, h.plan_auto_panel, 0, 0, try_binned, s);
             if (rc == SPMV_OK) {
                 h.auto_variant = SPMV_PANEL;
                 release_tiled();
@@ -472,7 +477,7 @@ int spmv_csr_plan_get(const spmv_csr_t *h, int variant, int32_t params[8])
         case SPMV_PANEL:
             if (!panel.ready) { set_error("spmv_csr_plan_get: panel is not planned"); return SPMV_ERR_NOT_PLANNED; }
             params[4] = panel.pw_bits; params[5] = panel.waves_per_launch;
-            params[6] = panel.binned_mode ? 4 : panel.sorted_mode ? 3 : (panel.lds_mode ? 2 : 1);
+            params[6] = panel.binned_mode ? (panel.scatter_mode ? 5 : 4) : panel.sorted_mode ? 3 : (panel.lds_mode ? 2 : 1);
             if (panel.sorted_mode) { params[4] = panel.sb_rows; params[5] = panel.sb_waves; }
             if (panel.binned_mode) { params[4] = panel.bin_rows; params[5] = 0; }
             return SPMV_OK;
@@ -541,6 +546,9 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
             return (int64_t)h->plan_xskip.nseg * 8 + ((int64_t)h->plan_xskip.nblocks + 1) * 4 +
                    (h->plan_xskip.slabs > 1 ? (int64_t)h->plan_xskip.nblocks * h->plan_xskip.slabs * 1024 * 8 : 0);
         case SPMV_PANEL:     // tile_ptr; packed/pvals REPLACE col_idx/vals byte for byte (sorted blocks: + the empty slots)
+            if (panel.binned_mode && panel.scatter_mode)   // panel-major: column 2 + value 4 + destination 4; bin-major: product 4 + accumulator 2; the lists
+                return panel.padded * (2 + 4 + 4) + panel.bm_entries * (4 + 2) + (int64_t)panel.nblocks * (2048 * 4 + 16) +
+                       ((int64_t)panel.npanels + 1) * 4;
             if (panel.binned_mode)   // two tables per tile, 16-bit columns and rows, the products written and read back; pvals REPLACES vals
                 return (int64_t)panel.nblocks * (2 * (int64_t)panel.npanels + 2) * 4 + panel.padded * (2 + 4 + 4) + h->nnz * 2;
             if (panel.sorted_mode)   // unit bases, block tables, the rows of the tail units, the empty slots of the units in use
@@ -579,6 +587,11 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
                       h->plan_wave.pieces, h->plan_wave.block_rows, (long long)h->plan_wave.blocks, (long long)h->plan_wave.win_blocks,
                       h->plan_wave.d_col16 ? 1 : 0);
     }
+    else if (variant == SPMV_PANEL && panel->ready && panel->binned_mode && panel->scatter_mode)
+        snprintf(buf, (size_t)n, "binned scattered_products bins=%d rows_per_bin=%d panels=%d panel_columns=%d nonzeros_per_tile=%.1f rows_with_spare_sums=%d flagged_bins=%d product_workgroups_per_panel=%d padded=%lld bin_entries=%lld",
+                 panel->nblocks, panel->bin_rows, panel->npanels, 1 << panel->pw_bits,
+                 panel->nblocks ? (double)h->nnz / ((double)panel->nblocks * panel->npanels) : 0.0, panel->long_rows, panel->flagged_tiles,
+                 panel->splits, (long long)panel->padded, (long long)panel->bm_entries);
     else if (variant == SPMV_PANEL && panel->ready && panel->binned_mode)
         snprintf(buf, (size_t)n, "binned bins=%d rows_per_bin=%d panels=%d panel_columns=%d nonzeros_per_tile=%.1f products_per_lane=%d long_rows=%d flagged_tiles=%d product_workgroups_per_panel=%d padded=%lld",
                  panel->nblocks, panel->bin_rows, panel->npanels, 1 << panel->pw_bits,
@@ -590,9 +603,9 @@ int spmv_csr_plan_describe(const spmv_csr_t *h, int variant, char *buf, int n)
                  h->nnz ? (double)panel->lines / (double)h->nnz : 0.0, (long long)panel->tail,
                  (long long)panel->wide_blocks, colsort_model_cost(*panel, h->nnz));
     else if (variant == SPMV_PANEL && panel->ready)
-        snprintf(buf, (size_t)n, "panel_columns=%d panels=%d row_blocks=%d waves_per_launch=%d launches=%d x_panels_in=%s",
+        snprintf(buf, (size_t)n, "panel_columns=%d panels=%d row_blocks=%d waves_per_launch=%d launches=%d x_panels_in=%s nonzeros_per_step=%d",
                  1 << panel->pw_bits, panel->npanels, panel->nblocks,
-                 panel->waves_per_launch, panel_launches(*panel), panel->lds_mode ? "LDS" : "L2");
+                 panel->waves_per_launch, panel_launches(*panel), panel->lds_mode ? "LDS" : "L2", panel->lds_mode ? 64 : 256 * panel->step_vecs);
     else if (variant == SPMV_XSKIP && h->plan_xskip.ready)
         snprintf(buf, (size_t)n, "output_blocks=%d segments=%d slabs_per_block=%d", h->plan_xskip.nblocks, h->plan_xskip.nseg,
                  h->plan_xskip.slabs);

@@ -25,6 +25,7 @@
 // csr_tiling_kernel (src/kernels/csr_tiling.cu:24-114): x tile in shared memory, tile values streamed.
 #include <climits>
 #include <cstdlib>
+#include <type_traits>
 #include "spmv_internal.hpp"
 
 namespace spmv {
@@ -51,7 +52,7 @@ int check(const char *what)
 
 // ---- plan kernels ------------------------------------------------------------------------------------------------
 // nonzeros of every panel: total[p] = sum over bins of the tile counts, rounded up to a multiple of 8 (16-byte loads)
-__global__ __launch_bounds__(256) void k_bin_panel_totals(int nb, int np, const int32_t *__restrict__ tile_ptr, int32_t *__restrict__ total)
+__global__ __launch_bounds__(256) void k_bin_panel_totals(int nb, int np, int round, const int32_t *__restrict__ tile_ptr, int32_t *__restrict__ total)
 {
     __shared__ int part[256];
     const int p = blockIdx.x;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void k_bin_panel_totals(int nb, int np, const 
         if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
         __syncthreads();
     }
-    if (threadIdx.x == 0) total[p] = (part[0] + 7) & ~7;
+    if (threadIdx.x == 0) total[p] = (part[0] + round - 1) & ~(round - 1);
 }
 // pm[b * np + p] = pbase[p] + (nonzeros of panel p in the bins before b): one workgroup per panel scans the bins
 __global__ __launch_bounds__(256) void k_bin_pm(int nb, int np, const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ pbase,
@@ -185,6 +186,314 @@ __global__ __launch_bounds__(kProdThreads) void k_bin_products(int splits, int64
         *reinterpret_cast<f4 *>(prod + k) = o0;
         *reinterpret_cast<f4 *>(prod + k + 4) = o1;
     }
+}
+
+
+// ==== the SCATTERED flavour (PanelPlan::scatter_mode): the products land in BIN-major order =============================
+// The flavour above lets the sum launch FETCH tile (b, p) from the panel-major products: a piece of <= 64 E products of one
+// tile per instruction group.  That is as good as the tiles are fat -- config 5's shard has 10-20 products per tile, so
+// nine lanes in ten idle and every tile costs its table entries (4.1 ms against the sweep's 3.0).  Here the PRODUCT launch
+// carries the permutation instead: it streams the panel-major entries (16-bit column, value, and the entry's bin-major
+// position: 10 B) and stores each product at that position -- a tile stays one contiguous run in both orders, and the
+// panel-major arrays are interleaved in blocks of 512 so that the 64 lanes of one store hold 64 CONSECUTIVE entries
+// (16-byte loads per lane AND whole runs per store).  The sum launch is then a pure stream per bin: 4 B of product + a
+// 16-bit ACCUMULATOR index, 256 entries per piece (four consecutive per lane), no tile table at all.  What keeps the
+// read-add-write of a step free of collisions is decided when the plan is made: entry k of every lane forms a step; the
+// j-th entry of a step that names a row already named in it gets the row's j-th spare accumulator (k_bs_accs), the spare
+// accumulators join the row's own at the end of the bin.  A bin that needs more spare accumulators than there are (kPool) is
+// flagged and adds with LDS atomics.
+constexpr int kBlk = 512;                  // interleave block of the panel-major arrays: lane l of a wavefront holds entries l, 64 + l, ...
+constexpr int kPool = 2048;                // spare accumulators of a bin
+constexpr int kBmPiece = 256;              // entries of the bin-major arrays per wavefront instruction group
+
+__device__ __forceinline__ int interleaved(int q) { return (q & ~(kBlk - 1)) | ((q & 63) << 3) | ((q >> 6) & 7); }
+
+// entries of every bin, rounded up to whole pieces (bbase is scanned afterwards)
+__global__ void k_bs_counts(int nb, int np, const int32_t *__restrict__ tile_ptr, int32_t *__restrict__ bcnt, int32_t *__restrict__ bbase)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+    const int n = tp[np] - tp[0];
+    bcnt[b] = n;
+    bbase[b] = (n + kBmPiece - 1) & ~(kBmPiece - 1);
+}
+
+// k_bin_fill for this flavour: rows at the bin-major (padded) position, the panel-major entry interleaved, and its destination
+__global__ __launch_bounds__(256) void k_bs_fill(int nb, int np, const int32_t *__restrict__ brow, const int32_t *__restrict__ row_ptr,
+                                                 const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
+                                                 const uint16_t *__restrict__ rowloc, const int32_t *__restrict__ tile_ptr,
+                                                 const int32_t *__restrict__ pm, const int32_t *__restrict__ bbase,
+                                                 uint16_t *__restrict__ c16, float *__restrict__ pvals, int32_t *__restrict__ dst,
+                                                 uint16_t *__restrict__ acc)
+{
+    extern __shared__ int cursor_all[];     // 4 x np
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= nb) return;
+    int *cursor = cursor_all + w * np;
+    const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+    const int32_t *qp = pm + (int64_t)b * np;
+    for (int p = lane; p < np; p += kWave) cursor[p] = tp[p];
+    const int s = row_ptr[brow[b]], e = row_ptr[brow[b + 1]];
+    const int shift = bbase[b] - tp[0];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = s; base < e; base += kWave) {
+        const int k = base + lane;
+        const bool valid = k < e;
+        int col = 0, rl = 0;
+        float v = 0.0f;
+        if (valid) {
+            col = col_idx[k];
+            rl = rowloc[k];
+            v = vals[k];
+        }
+        const int p = col >> kPwBits;
+        int dest = 0;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int pl = __shfl(p, leader);
+            const unsigned long long m = __ballot(valid && p == pl);
+            const int first = cursor[pl];
+            if (valid && p == pl) dest = first + __popcll(m & lt);
+            if (lane == leader) cursor[pl] = first + __popcll(m);
+            todo &= ~m;
+        }
+        if (valid) {
+            acc[dest + shift] = (uint16_t)rl;                  // (k_bs_accs turns rows into accumulators)
+            const int q = interleaved(qp[p] + (dest - tp[p]));
+            c16[q] = (uint16_t)(col & (kPw - 1));
+            pvals[q] = v;
+            dst[q] = dest + shift;
+        }
+    }
+}
+
+// Accumulators of one bin (a wavefront per bin).  Step (piece, k) of the sum launch holds entries piece * 256 + 4 l + k of the
+// bin, l = 0..63.  occ = how many lower lanes of the step name the same row.  Pass A: the deepest occ of every row; then the
+// spare accumulators are dealt out (occ of them per row) and the bin's list written; pass B: entry -> row (occ 0) or the
+// row's spare accumulator number occ - 1.  LDS: tag[RB] (who wrote last) and deep[RB] (max occ, then the first spare).
+template <int RB>
+__global__ __launch_bounds__(kWave) void k_bs_accs(const int32_t *__restrict__ brow, const int32_t *__restrict__ bbase,
+                                                   const int32_t *__restrict__ bcnt, uint16_t *__restrict__ acc,
+                                                   int32_t *__restrict__ nlong, uint32_t *__restrict__ lrow, int32_t *__restrict__ stats)
+{
+    extern __shared__ int lds_i[];
+    int *tag = lds_i, *deep = lds_i + RB;
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int nrows = brow[b + 1] - brow[b];
+    const int base = bbase[b], n = bcnt[b];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int i = lane; i < RB; i += kWave) deep[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    // occ of this lane's entry in its step
+    auto occurrence = [&](bool valid, int r) {
+        if (valid) reinterpret_cast<volatile int *>(tag)[r] = lane;
+        __builtin_amdgcn_wave_barrier();
+        const int wtag = valid ? reinterpret_cast<volatile int *>(tag)[r] : lane;
+        unsigned long long losers = __ballot(valid && wtag != lane);
+        int occ = 0;
+        while (losers) {
+            const int leader = __ffsll((long long)losers) - 1;
+            const int rl = __shfl(r, leader);
+            const unsigned long long m = __ballot(valid && r == rl);
+            if (valid && r == rl) occ = __popcll(m & lt);
+            losers &= ~m;
+        }
+        return occ;
+    };
+    int deepest = 0;
+    for (int e0 = 0; e0 < n; e0 += kBmPiece)
+        for (int k = 0; k < 4; ++k) {
+            const int i = e0 + 4 * lane + k;
+            const bool valid = i < n;
+            const int r = valid ? (int)acc[base + i] : 0;
+            const int occ = occurrence(valid, r);
+            if (occ > 0) atomicMax(&deep[r], occ);
+            deepest = occ > deepest ? occ : deepest;
+        }
+    if (__ballot(deepest > 0) == 0ull) {                            // no row twice in any step
+        if (lane == 0) nlong[b] = 0;
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the spare accumulators, rows ascending; the list: row << 17 | first << 6 | count
+    int used = 0, listed = 0;
+    bool over = false;
+    for (int r0 = 0; r0 < nrows && !over; r0 += kWave) {
+        const int r = r0 + lane;
+        const int need = r < nrows ? deep[r] : 0;
+        int pre = need;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int t = __shfl_up(pre, d);
+            if (lane >= d) pre += t;
+        }
+        const int total = __shfl(pre, kWave - 1);
+        if (used + total > kPool) { over = true; break; }
+        const int first = used + pre - need;
+        const unsigned long long lm = __ballot(need > 0);
+        if (need > 0) {
+            deep[r] = first;
+            lrow[(int64_t)b * kPool + listed + __popcll(lm & lt)] = ((uint32_t)r << 17) | ((uint32_t)first << 6) | (uint32_t)need;
+        }
+        used += total;
+        listed += __popcll(lm);
+    }
+    if (over) {                                                     // flagged: the rows stay rows, the sum launch adds with atomics
+        if (lane == 0) { nlong[b] = -1; atomicAdd(&stats[0], 1); }
+        return;
+    }
+    if (lane == 0) { nlong[b] = listed; atomicAdd(&stats[1], listed); }
+    __builtin_amdgcn_wave_barrier();
+    for (int e0 = 0; e0 < n; e0 += kBmPiece)
+        for (int k = 0; k < 4; ++k) {
+            const int i = e0 + 4 * lane + k;
+            const bool valid = i < n;
+            const int r = valid ? (int)acc[base + i] : 0;
+            const int occ = occurrence(valid, r);
+            if (occ > 0) acc[base + i] = (uint16_t)(RB + deep[r] + occ - 1);
+        }
+}
+
+// launch 1 of this flavour: products in panel order, stored in bin order
+__global__ __launch_bounds__(kProdThreads) void k_bs_products(int splits, int64_t cols, const int32_t *__restrict__ pbase,
+                                                              const uint16_t *__restrict__ c16, const float *__restrict__ pvals,
+                                                              const int32_t *__restrict__ dst, const float *__restrict__ x,
+                                                              float *__restrict__ prod)
+{
+    extern __shared__ __attribute__((aligned(16))) float xp[];      // the panel: kPw floats
+    using i4 = int __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x / splits, part = blockIdx.x - p * splits;
+    const int64_t g0 = (int64_t)p << kPwBits;
+    if (g0 + kPw + 3 < cols) {                                      // workgroup-uniform
+#pragma unroll
+        for (int i = tid * 4; i < kPw; i += kProdThreads * 4) __builtin_amdgcn_global_load_lds(x + g0 + i, xp + i, 16, 0, 0);
+    } else {
+        for (int i = tid; i < kPw; i += kProdThreads) xp[i] = g0 + i < cols ? x[g0 + i] : 0.0f;
+    }
+    const int a0 = pbase[p], b0 = pbase[p + 1];                     // multiples of kBlk
+    const int units = (b0 - a0) / kBlk, per = (units + splits - 1) / splits;
+    const int a = a0 + part * per * kBlk;
+    int b = a + per * kBlk;
+    if (b > b0) b = b0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): this wave's pieces of the panel have landed
+    __syncthreads();
+#ifdef SPMV_BS_AB_NOSTORE
+    float keep = 0.0f;
+#endif
+    for (int k = a + tid * 8; k < b; k += kProdThreads * 8) {       // a wavefront: one interleave block per trip
+        const u4 c = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(c16 + k));
+        const f4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(pvals + k));
+        const f4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(pvals + k + 4));
+        const i4 d0 = __builtin_nontemporal_load(reinterpret_cast<const i4 *>(dst + k));
+        const i4 d1 = __builtin_nontemporal_load(reinterpret_cast<const i4 *>(dst + k + 4));
+#ifdef SPMV_BS_AB_NOSTORE      // (A/B, wrong results: everything but the stores)
+        keep += xp[c.x & 0xffffu] * v0.x + xp[c.x >> 16] * v0.y + xp[c.y & 0xffffu] * v0.z + xp[c.y >> 16] * v0.w + xp[c.z & 0xffffu] * v1.x +
+                xp[c.z >> 16] * v1.y + xp[c.w & 0xffffu] * v1.z + xp[c.w >> 16] * v1.w + (float)(d0.x ^ d0.y ^ d0.z ^ d0.w ^ d1.x ^ d1.y ^ d1.z ^ d1.w);
+#else
+        prod[d0.x] = xp[c.x & 0xffffu] * v0.x;                      // store j of the 64 lanes: 64 consecutive entries of the panel
+        prod[d0.y] = xp[c.x >> 16] * v0.y;
+        prod[d0.z] = xp[c.y & 0xffffu] * v0.z;
+        prod[d0.w] = xp[c.y >> 16] * v0.w;
+        prod[d1.x] = xp[c.z & 0xffffu] * v1.x;
+        prod[d1.y] = xp[c.z >> 16] * v1.y;
+        prod[d1.z] = xp[c.w & 0xffffu] * v1.z;
+        prod[d1.w] = xp[c.w >> 16] * v1.w;
+#endif
+    }
+#ifdef SPMV_BS_AB_NOSTORE
+    prod[tid & 15] = keep;
+#endif
+}
+
+// launch 2 of this flavour: a wavefront per bin, its products and accumulator numbers one contiguous stream
+template <int RB>
+__global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ brow, const int32_t *__restrict__ bbase,
+                                                   const int32_t *__restrict__ bcnt, const uint16_t *__restrict__ acc,
+                                                   const float *__restrict__ prod, const int32_t *__restrict__ nlong,
+                                                   const uint32_t *__restrict__ lrow, float *__restrict__ y, uint32_t prod_bytes,
+                                                   uint32_t acc_bytes)
+{
+#ifndef SPMV_BS_DEPTH
+#define SPMV_BS_DEPTH 4
+#endif
+    constexpr int kDummy = RB + kPool, kD = SPMV_BS_DEPTH;           // pieces per register set (two sets in flight)
+    extern __shared__ float sums[];                                 // RB + kPool + kWave
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int row0 = brow[b], nrows = brow[b + 1] - row0;
+    const int base = bbase[b], pieces = (bcnt[b] + kBmPiece - 1) / kBmPiece, nl = nlong[b];
+    for (int i = lane; i < kDummy; i += kWave) sums[i] = 0.0f;
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(prod), 0, (int)prod_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(acc), 0, (int)acc_bytes, 0x00020000);
+    using u4v = decltype(__builtin_amdgcn_raw_buffer_load_b128(pr, 0, 0, 0));
+    using u2v = decltype(__builtin_amdgcn_raw_buffer_load_b64(rr, 0, 0, 0));
+    struct Set { u4v v[kD]; u2v a[kD]; };                           // as loaded: unpacking here would wait for the loads at once
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // (the table numbers are in: the waits below count piece loads only)
+    auto issue = [&](int pi0, Set &c) {                             // no branch: a piece past the end reads on (slack) and counts for nothing
+#pragma unroll
+        for (int u = 0; u < kD; ++u) {
+            const unsigned at = (unsigned)base + (unsigned)(pi0 + u) * kBmPiece;
+#ifdef SPMV_BS_AB_NOLOAD       // (A/B, wrong results: the LDS side alone)
+            c.v[u] = u4v{at, at, at, at};
+            c.a[u] = u2v{(at * 2654435761u) & 0x0fff0fffu, (at * 40503u + lane * 977u) & 0x0fff0fffu};
+#else
+            c.v[u] = __builtin_amdgcn_raw_buffer_load_b128(pr, lane * 16, (int)(at * 4u), 0);
+            c.a[u] = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, (int)(at * 2u), 0);
+#endif
+            // the SAME order of loads before the loop and inside it: the wait counts are static, and a first trip that needs
+            // "everything" (the scheduler had turned the sets round) makes every trip wait for everything
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto consume = [&](int pi0, Set &c, auto flagged) {
+#pragma unroll
+        for (int u = 0; u < kD; ++u) {
+            const bool live = pi0 + u < pieces;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                           // step k: no accumulator twice (k_bs_accs)
+                const unsigned w = c.a[u][k >> 1];
+                const int a = live ? (int)((k & 1) ? w >> 16 : w & 0xffffu) : kDummy;
+                const float v = __uint_as_float(c.v[u][k]);
+#ifdef SPMV_BS_AB_NOLDS        // (A/B, wrong results: the memory side alone)
+                sums[kDummy + (lane & 63)] = __uint_as_float(__float_as_uint(v) ^ (unsigned)a);
+#else
+                if (decltype(flagged)::value) atomicAdd(&sums[a], v);
+                else sums[a] += v;
+#endif
+            }
+        }
+    };
+    // two register sets, both in flight at the top of the loop (as in k_bin_sums)
+    auto stream = [&](auto flagged) {
+        Set sa, sb;
+        __builtin_amdgcn_sched_barrier(0);
+        issue(0, sa);
+        issue(kD, sb);
+        for (int pi0 = 0; pi0 < pieces; pi0 += 2 * kD) {
+            // (the scheduler is kept from moving a set's loads into the other set's sums: the waits would then drain both)
+            __builtin_amdgcn_sched_barrier(0);
+            consume(pi0, sa, flagged);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(pi0 + 2 * kD, sa);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(pi0 + kD, sb, flagged);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(pi0 + 3 * kD, sb);
+        }
+    };
+    if (nl >= 0) stream(std::false_type());
+    else stream(std::true_type());                                  // flagged bin (wave-uniform): LDS atomics
+    for (int i = lane; i < nl; i += kWave) {                        // the spare accumulators join their rows, in order
+        const uint32_t w = lrow[(int64_t)b * kPool + i];
+        const int row = (int)(w >> 17), first = RB + (int)((w >> 6) & 0x7ffu), cnt = (int)(w & 63u);
+        float t = sums[row];
+        for (int c = 0; c < cnt; ++c) t += sums[first + c];
+        sums[row] = t;
+    }
+    for (int i = lane; i < nrows; i += kWave) y[row0 + i] = sums[i];
 }
 
 // ---- launch 2: sums per bin -----------------------------------------------------------------------------------------
@@ -474,6 +783,12 @@ void destroy_binned(PanelPlan &p)
     if (p.d_lptr) (void)hipFree(p.d_lptr);
     if (p.d_lrow) (void)hipFree(p.d_lrow);
     if (p.d_lcnt) (void)hipFree(p.d_lcnt);
+    if (p.d_dst) (void)hipFree(p.d_dst);
+    if (p.d_bbase) (void)hipFree(p.d_bbase);
+    if (p.d_bcnt) (void)hipFree(p.d_bcnt);
+    if (p.d_nlong) (void)hipFree(p.d_nlong);
+    p.d_dst = p.d_bbase = p.d_bcnt = p.d_nlong = nullptr;
+    p.scatter_mode = false;
     p.d_lptr = p.d_lcnt = nullptr;
     p.d_lrow = nullptr;
     p.d_c16 = p.d_r16 = nullptr;
@@ -490,9 +805,98 @@ double binned_tile_nonzeros(const spmv_csr &h, int bin_rows)
     return (double)h.nnz / (nb * np);
 }
 
-// want_rows: 0 = the rule (8192 rows per bin where that still leaves two bins per resident wavefront, else 4096), 4096 | 8192
-int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s)
+
+// the rest of plan_binned for the scattered flavour: bin-major positions, the fill, the accumulators
+static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPtr<int32_t> &brow, DevPtr<int32_t> &tiles,
+                        DevPtr<int32_t> &pm, DevPtr<int32_t> &pbase, hipStream_t s)
 {
+    const int nb = p.nblocks, np = p.npanels;
+    int rc;
+    DevPtr<int32_t> bbase, bcnt, total, dst, nlong, stats;
+    DevPtr<uint32_t> lrow;
+    DevPtr<uint16_t> rowloc, c16, acc;
+    DevPtr<float> pvals, prod;
+    SPMV_HIP_TRY(bbase.alloc((size_t)nb + 1));
+    SPMV_HIP_TRY(bcnt.alloc((size_t)nb));
+    SPMV_HIP_TRY(total.alloc(1));
+    k_bs_counts<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s>>>(nb, np, tiles.p, bcnt.p, bbase.p);
+    if ((rc = check("k_bs_counts"))) return rc;
+    if ((rc = exclusive_scan_i32(bbase.p, nb, total.p, s))) return rc;
+    int32_t bm = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&bm, total.p, sizeof bm, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipMemcpyAsync(bbase.p + nb, total.p, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    if (bm < 0 || (int64_t)bm > (1ll << 30) - 64) {   // (h.nnz + 256 per bin: the check of plan_binned leaves this much)
+        set_error("spmv_csr_plan(panel, binned, scattered products): %d bins pad nnz %lld beyond 2^30 entries", nb, (long long)h.nnz);
+        return SPMV_ERR_INVALID;
+    }
+    const size_t nslot = (size_t)padded + 8, bslot = (size_t)bm + 16;       // (entry bm: where the pad slots of the panels store)
+    SPMV_HIP_TRY(c16.alloc(nslot));
+    SPMV_HIP_TRY(pvals.alloc(nslot));
+    SPMV_HIP_TRY(dst.alloc(nslot));
+    SPMV_HIP_TRY(prod.alloc(bslot));
+    SPMV_HIP_TRY(acc.alloc(bslot));
+    SPMV_HIP_TRY(rowloc.alloc((size_t)h.nnz + 8));
+    SPMV_HIP_TRY(nlong.alloc((size_t)nb));
+    SPMV_HIP_TRY(lrow.alloc((size_t)nb * kPool));
+    SPMV_HIP_TRY(stats.alloc(2));
+    SPMV_HIP_TRY(hipMemsetAsync(c16.p, 0, sizeof(uint16_t) * nslot, s));     // the pad slots of every panel: column 0, value 0 ...
+    SPMV_HIP_TRY(hipMemsetAsync(pvals.p, 0, sizeof(float) * nslot, s));
+    SPMV_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dst.p), bm, nslot, s));   // ... stored where nothing reads
+    SPMV_HIP_TRY(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(acc.p), (unsigned short)(rb + kPool), bslot, s));   // pad entries: the dummy word
+    SPMV_HIP_TRY(hipMemsetAsync(prod.p, 0, sizeof(float) * bslot, s));
+    SPMV_HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(int32_t) * 2, s));
+    int32_t st[2] = {0, 0};
+    if (h.nnz > 0) {
+        if ((rc = panel_rowloc(h, brow.p, nb, rowloc.p, s))) return rc;
+        k_bs_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), sizeof(int) * 4 * (size_t)np, s>>>(
+            nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, tiles.p, pm.p, bbase.p, c16.p, pvals.p, dst.p, acc.p);
+        if ((rc = check("k_bs_fill"))) return rc;
+        const size_t lds = sizeof(int) * 2 * (size_t)rb;
+        if (rb == 8192) {
+            static LdsOptIn optin;
+            if ((rc = optin.ensure(reinterpret_cast<const void *>(&k_bs_accs<8192>), h.device, (int)lds))) return rc;
+            k_bs_accs<8192><<<dim3((unsigned)nb), dim3(kWave), lds, s>>>(brow.p, bbase.p, bcnt.p, acc.p, nlong.p, lrow.p, stats.p);
+        } else {
+            k_bs_accs<4096><<<dim3((unsigned)nb), dim3(kWave), lds, s>>>(brow.p, bbase.p, bcnt.p, acc.p, nlong.p, lrow.p, stats.p);
+        }
+        if ((rc = check("k_bs_accs"))) return rc;
+        SPMV_HIP_TRY(hipMemcpyAsync(st, stats.p, sizeof st, hipMemcpyDeviceToHost, s));
+    } else {
+        SPMV_HIP_TRY(hipMemsetAsync(nlong.p, 0, sizeof(int32_t) * (size_t)nb, s));
+    }
+    const int cus = device_cus(h.device);
+    p.splits = np >= 2 * cus ? 1 : (2 * cus + np - 1) / np;
+    if (const char *e = getenv("SPMV_BINNED_SPLITS")) { const int v = atoi(e); if (v > 0) p.splits = v; }
+    if ((rc = stamp_values(h, s, p.stamp))) return rc;
+    SPMV_HIP_TRY(hipStreamSynchronize(s));   // the temporaries (tiles, pm, rowloc) are freed on return
+    p.padded = padded;
+    p.bm_entries = bm;
+    p.flagged_tiles = st[0];                 // (bins, in this flavour)
+    p.long_rows = st[1];
+    p.d_c16 = c16.release();
+    p.d_pvals = pvals.release();
+    p.d_dst = dst.release();
+    p.d_prod = prod.release();
+    p.d_r16 = acc.release();
+    p.d_pbase = pbase.release();
+    p.d_bbase = bbase.release();
+    p.d_bcnt = bcnt.release();
+    p.d_nlong = nlong.release();
+    p.d_lrow = lrow.release();
+    p.d_brow = brow.release();
+    p.ready = true;
+    return SPMV_OK;
+}
+
+// want_rows: 0 = the rule (8192 rows per bin where that still leaves two bins per resident wavefront, else 4096), 4096 | 8192
+// scatter: the flavour whose product launch stores in bin order (thin tiles)
+int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, bool scatter, hipStream_t s)
+{
+    if (scatter && want_rows != 0 && want_rows != 4096 && want_rows != 8192) {
+        set_error("spmv_csr_plan(panel, binned, scattered products): rows per bin %d (4096 or 8192)", want_rows);
+        return SPMV_ERR_INVALID;
+    }
     if (want_rows != 0 && want_rows != 1024 && want_rows != 2048 && want_rows != 4096 && want_rows != 8192) {
         set_error("spmv_csr_plan(panel, binned): rows per bin %d (1024, 2048, 4096 or 8192)", want_rows);
         return SPMV_ERR_INVALID;
@@ -509,8 +913,9 @@ int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s)
     }
     const int cus = device_cus(h.device);
     int rb = want_rows;
-    if (rb == 0) rb = 4096;     // eight wavefronts per CU (8192: four; measured slower at every size tried: DESIGN.md)
+    if (rb == 0) rb = scatter ? 8192 : 4096;     // eight wavefronts per CU (8192: four; measured slower at every size tried: DESIGN.md); scattered: fatter tiles win
     p.binned_mode = true;
+    p.scatter_mode = scatter;
     p.bin_rows = rb;
     p.pw_bits = kPwBits;
     p.npanels = np;
@@ -525,6 +930,7 @@ int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s)
     // (wavefronts that carry equal loads finish together; the cuts aim at 0.8 rb rows so that hardly any needs splitting)
     const int64_t slots = (int64_t)cus * ((rb + kSpare + kWave) * 4 * kSumWaves <= 80 * 1024 ? 2 : 1) * kSumWaves;
     int64_t nb0 = slots * ((h.rows * 5 / 4 + (int64_t)rb * slots - 1) / ((int64_t)rb * slots));
+    if (scatter) nb0 = (h.rows * 9 / 8 + rb - 1) / rb;        // (thin tiles: as many rows per bin as the cuts allow)
     if (nb0 > h.rows) nb0 = h.rows;
     DevPtr<int32_t> brow;
     int rc = panel_row_blocks(h, nb0, rb, s, brow, &p.nblocks);
@@ -542,7 +948,7 @@ int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s)
     SPMV_HIP_TRY(pbase.alloc((size_t)np + 1));
     SPMV_HIP_TRY(total.alloc(1));
     if ((rc = panel_tile_ptr(h, brow.p, nb, kPwBits, np, tiles.p, s))) return rc;
-    k_bin_panel_totals<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, tiles.p, pbase.p);
+    k_bin_panel_totals<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, scatter ? kBlk : 8, tiles.p, pbase.p);
     if ((rc = check("k_bin_panel_totals"))) return rc;
     if ((rc = exclusive_scan_i32(pbase.p, np, total.p, s))) return rc;
     int32_t padded = 0;
@@ -551,6 +957,7 @@ int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s)
     SPMV_HIP_TRY(hipStreamSynchronize(s));
     k_bin_pm<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, tiles.p, pbase.p, pm.p);
     if ((rc = check("k_bin_pm"))) return rc;
+    if (scatter) return plan_scatter(h, p, rb, padded, brow, tiles, pm, pbase, s);
     const size_t nslot = (size_t)padded + 264;                             // (a piece reads up to 256 entries past a tile's end)
     SPMV_HIP_TRY(c16.alloc(nslot));
     SPMV_HIP_TRY(pvals.alloc(nslot));
@@ -638,9 +1045,27 @@ static int launch_sums(const spmv_csr &h, const PanelPlan &p, float *y, hipStrea
     return p.wide_pieces ? launch_sums_e<RB, 4>(h, p, y, s) : launch_sums_e<RB, 2>(h, p, y, s);
 }
 
+template <int RB>
+static int launch_bs_sums(const spmv_csr &h, const PanelPlan &p, float *y, hipStream_t s)
+{
+    const size_t lds = sizeof(float) * (size_t)(RB + kPool + kWave);
+    k_bs_sums<RB><<<dim3((unsigned)p.nblocks), dim3(kWave), lds, s>>>(p.d_brow, p.d_bbase, p.d_bcnt, p.d_r16, p.d_prod, p.d_nlong, p.d_lrow, y,
+                                                                      (uint32_t)((p.bm_entries + 16) * 4), (uint32_t)((p.bm_entries + 16) * 2));
+    return check("k_bs_sums");
+}
+
 int launch_binned(const spmv_csr &h, const PanelPlan &p, const float *x, float *y, hipStream_t s)
 {
     if (p.nblocks == 0) return SPMV_OK;   // no rows
+    if (p.scatter_mode) {
+        const size_t lds = sizeof(float) * (size_t)kPw;
+        static LdsOptIn optin;
+        if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_bs_products), h.device, (int)lds)) return rc;
+        k_bs_products<<<dim3((unsigned)(p.npanels * p.splits)), dim3(kProdThreads), lds, s>>>(p.splits, h.cols, p.d_pbase, p.d_c16,
+                                                                                              p.d_pvals, p.d_dst, x, p.d_prod);
+        if (int rc = check("k_bs_products")) return rc;
+        return p.bin_rows == 8192 ? launch_bs_sums<8192>(h, p, y, s) : launch_bs_sums<4096>(h, p, y, s);
+    }
     {
         const size_t lds = sizeof(float) * (size_t)kPw;
         static LdsOptIn optin;

@@ -51,11 +51,13 @@ constexpr unsigned kColMask = (1u << kColBits) - 1;
 constexpr unsigned kJoinBit = 1u << kColBits;   // this nonzero and the one 4 places before it in its tile share a row
 constexpr int kRowShift = kColBits + 1;
 constexpr int kWavesPerWg = 2;             // 76 KiB of LDS per workgroup -> 2 workgroups = 4 waves per CU
-#ifndef SPMV_PANEL_VEC
-#define SPMV_PANEL_VEC 8
-#endif
-constexpr int kVec = SPMV_PANEL_VEC;       // 16-byte vectors per lane per step and per array
-constexpr int kStep = kWave * 4 * kVec;    // 2048 nonzeros per wave per step (8 vectors: +4 % over 4, A/B on c3/c4)
+// 16-byte vectors per lane, step and array: a step of the sweep is 256 x VEC nonzeros of a wavefront's stream.  Two
+// instantiations, chosen when the plan is made (PanelPlan::step_vecs): 8 where the tiles are fat (+4 % over 4 at configs 3
+// and 4), 4 where a step of 2048 would span many panels -- config 5's shard, 128 nonzeros per tile: the gathers of ONE step
+// then cover 16 panels = 8 MiB of x, twice an L2, and the wavefronts of an XCD stop sharing lines (3.02 -> 2.41 ms,
+// profiles/r04_panel_step_size.jsonl; 6: 2.61, 3: 2.44, 2: 2.53, 1: 2.92)
+constexpr int kVecMax = 8;
+constexpr int kStepMax = kWave * 4 * kVecMax;
 constexpr int kMaxPanels = 4096;
 
 using u4 = unsigned __attribute__((ext_vector_type(4)));
@@ -239,10 +241,12 @@ __global__ __launch_bounds__(256) void k_panel_joins(const int32_t *__restrict__
 }
 
 // ---- the multiply -------------------------------------------------------------------------------------------
+template <int kVec>
 struct StepRegs {     // one step of the stream, as loaded
     u4 c[kVec];
     f4 v[kVec];
 };
+template <int kVec>
 struct GatherRegs {   // one step between its gathers and its sums
     float xv[kVec][4];
     float val[kVec][4];
@@ -252,8 +256,9 @@ struct GatherRegs {   // one step between its gathers and its sums
     bool interior;
 };
 
+template <int kVec>
 __device__ __forceinline__ void panel_load(const u4 *__restrict__ c4, const f4 *__restrict__ v4, int base, int lane,
-                                           StepRegs &r)
+                                           StepRegs<kVec> &r)
 {
 #pragma unroll
     for (int j = 0; j < kVec; ++j) {
@@ -263,6 +268,7 @@ __device__ __forceinline__ void panel_load(const u4 *__restrict__ c4, const f4 *
     }
 }
 
+template <int kVec>
 __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, const int32_t *__restrict__ brow,
                                                               const int32_t *__restrict__ row_ptr,
                                                               const int32_t *__restrict__ tile_ptr,
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
                                                               const float *__restrict__ x, float *__restrict__ y,
                                                               int np, int pw_bits)
 {
+    constexpr int kStep = kWave * 4 * kVec;
     __shared__ float ys_all[kWavesPerWg][kRw];
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     const int wb = wb0 + blockIdx.x * kWavesPerWg + w;
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
     //   gather(step): panel of every element, issue the x loads, keep what the sums need (the stream registers are
     //                 free for the next load right after);
     //   sum(step):    add into the wave's LDS sums.
-    auto gather = [&](int base, const StepRegs &r, GatherRegs &g) {
+    auto gather = [&](int base, const StepRegs<kVec> &r, GatherRegs<kVec> &g) {
         // panel of every element: pdone + the boundaries inside this step that lie at or before it
         int pv[kVec][4];
 #pragma unroll
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
             }
         }
     };
-    auto sum = [&](int base, const GatherRegs &g) {
+    auto sum = [&](int base, const GatherRegs<kVec> &g) {
 #pragma unroll
         for (int j = 0; j < kVec; ++j) {
             if (g.simple[j]) {
@@ -357,8 +364,8 @@ __global__ __launch_bounds__(kWave *kWavesPerWg) void k_panel(int wb0, int wb1, 
         }
     };
 
-    StepRegs s0, s1;
-    GatherRegs g0, g1;
+    StepRegs<kVec> s0, s1;
+    GatherRegs<kVec> g0, g1;
     auto step_base = [&](int st) { return k0 + st * kStep; };
     if (nsteps > 0) {
         panel_load(c4, v4, step_base(0), lane, s0);
@@ -533,7 +540,7 @@ int refresh_panel(spmv_csr &h, PanelPlan &dst, hipStream_t s)
 {
     if (!dst.ready) return build_panel(h, dst, 0, 0, 0, s);
     if (dst.stamp.gen == h.values_gen) return SPMV_OK;
-    if (dst.binned_mode) return build_panel(h, dst, dst.bin_rows, 0, 4, s);
+    if (dst.binned_mode) return build_panel(h, dst, dst.bin_rows, 0, dst.scatter_mode ? 5 : 4, s);
     if (dst.sorted_mode) return build_panel(h, dst, dst.sb_rows, dst.sb_waves, 3, s);
     return build_panel(h, dst, dst.pw_bits, dst.waves_per_launch, dst.lds_mode ? 2 : 1, s);
 }
@@ -545,13 +552,14 @@ int plan_panel_with(spmv_csr &h, int want_bits, int want_waves, int want_mode, h
 
 // want_mode: 0 = the rule below, 1 = panels through L2 (k_panel), 2 = panels staged in LDS (k_panel_lds),
 //            3 = sorted blocks (kernels_colsort.hip; SPMV_PANEL_SORTED=1 makes it the rule's answer),
-//            4 = binned (kernels_binned.hip: products streamed in panel order, summed per row block; want_bits = rows per bin)
+//            4 = binned (kernels_binned.hip: products streamed in panel order, summed per row block; want_bits = rows per bin),
+//            5 = binned, the products stored in bin order by the product launch (thin tiles)
 int build_panel(spmv_csr &h, PanelPlan &dst, int want_bits, int want_waves, int want_mode, hipStream_t s)
 {
     destroy_panel(dst);
     PanelPlan p;
-    if (want_mode == 4) {      // binned: two streaming launches, no gather from memory (kernels_binned.hip)
-        const int rc = plan_binned(h, p, want_bits, s);
+    if (want_mode == 4 || want_mode == 5) {      // binned: two streaming launches, no gather from memory (kernels_binned.hip)
+        const int rc = plan_binned(h, p, want_bits, want_mode == 5, s);
         if (rc) { destroy_panel(p); return rc; }
         dst = p;
         return SPMV_OK;
@@ -581,7 +589,7 @@ int build_panel(spmv_csr &h, PanelPlan &dst, int want_bits, int want_waves, int 
         if (want_mode == 2) lds = true;
         p.lds_mode = lds;
     }
-    if (h.nnz > (int64_t)INT_MAX - 4 * kStep) {
+    if (h.nnz > (int64_t)INT_MAX - 4 * kStepMax) {
         set_error("spmv_csr_plan(panel): nnz %lld too close to 2^31 for one handle", (long long)h.nnz);
         return SPMV_ERR_INVALID;
     }
@@ -630,12 +638,15 @@ int build_panel(spmv_csr &h, PanelPlan &dst, int want_bits, int want_waves, int 
     DevPtr<int32_t> brow;
     int rc = panel_row_blocks(h, nb0, cap, s, brow, &p.nblocks);
     if (rc) return rc;
+    // the step of the sweep: 1024 nonzeros where a step of 2048 would span eight tiles or more (see kVecMax)
+    p.step_vecs = (double)h.nnz < 256.0 * (double)p.nblocks * (double)p.npanels ? 4 : 8;
+    if (const char *e = getenv("SPMV_PANEL_STEP")) { const int v = atoi(e); if (v == 4 || v == 8) p.step_vecs = v; }
 
     DevPtr<uint32_t> packed;
     DevPtr<float> pvals;
     DevPtr<int32_t> tiles;
     DevPtr<uint16_t> rowloc;
-    const size_t slots = (size_t)h.nnz + 2 * kStep + 8;   // the last step of a block reads past its end
+    const size_t slots = (size_t)h.nnz + 2 * kStepMax + 8;   // the last step of a block reads past its end
     SPMV_HIP_TRY(packed.alloc(slots));
     SPMV_HIP_TRY(pvals.alloc(slots));
     SPMV_HIP_TRY(tiles.alloc((size_t)p.nblocks * (size_t)(p.npanels + 1)));
@@ -703,8 +714,12 @@ int launch_panel_plan(const spmv_csr &h, const PanelPlan &p, const float *x, flo
     for (int b0 = 0; b0 < p.nblocks; b0 += share) {
         const int b1 = b0 + share < p.nblocks ? b0 + share : p.nblocks;
         const int g = (b1 - b0 + kWavesPerWg - 1) / kWavesPerWg;
-        k_panel<<<dim3((unsigned)g), dim3(kWave * kWavesPerWg), 0, s>>>(b0, b1, p.d_brow, h.d_row_ptr, p.d_tile_ptr,
-                                                                        p.d_packed, p.d_pvals, x, y, p.npanels, p.pw_bits);
+        if (p.step_vecs == 4)
+            k_panel<4><<<dim3((unsigned)g), dim3(kWave * kWavesPerWg), 0, s>>>(b0, b1, p.d_brow, h.d_row_ptr, p.d_tile_ptr,
+                                                                               p.d_packed, p.d_pvals, x, y, p.npanels, p.pw_bits);
+        else
+            k_panel<8><<<dim3((unsigned)g), dim3(kWave * kWavesPerWg), 0, s>>>(b0, b1, p.d_brow, h.d_row_ptr, p.d_tile_ptr,
+                                                                               p.d_packed, p.d_pvals, x, y, p.npanels, p.pw_bits);
         const int rc = check_launch("k_panel");
         if (rc) return rc;
     }

@@ -104,6 +104,7 @@ struct PanelPlan {
     int npanels = 0;
     int nblocks = 0;               // row blocks (<= 8192 rows, equal nonzero counts) = wavefronts of work
     int waves_per_launch = 0;      // what is resident at once: one launch = one sweep in step
+    int step_vecs = 8;             // 16-byte vectors per lane and step of the sweep (8 | 4: thin tiles, kernels_panel.hip kVecMax)
     uint32_t *d_packed = nullptr;  // [nnz + slack] row_in_block << 18 | join << 17 | column_in_panel (kernels_panel.hip)
     float *d_pvals = nullptr;      // [nnz + slack] values in the same order (a COPY: re-plan after changing vals)
     int32_t *d_tile_ptr = nullptr; // [nblocks * (npanels + 1)]
@@ -142,6 +143,14 @@ struct PanelPlan {
     int32_t *d_lptr = nullptr;     // [nblocks + 1] first long row of every bin in d_lrow / d_lcnt
     uint32_t *d_lrow = nullptr;    // [long_rows] row in bin << 16 | first spare slot
     int32_t *d_lcnt = nullptr;     // [long_rows] spare slots of the row
+    // ... its scattered flavour: the product launch stores in bin order (d_dst), the sum launch streams d_prod + d_r16 (here:
+    // accumulator numbers) bin by bin; d_lrow = [nblocks * 2048] row << 17 | first spare accumulator << 6 | how many
+    bool scatter_mode = false;
+    int32_t *d_dst = nullptr;      // [padded] bin-major position of every panel-major entry (both interleaved in blocks of 512)
+    int32_t *d_bbase = nullptr;    // [nblocks + 1] first entry of every bin in d_prod / d_r16 (multiples of 256)
+    int32_t *d_bcnt = nullptr;     // [nblocks] entries of the bin
+    int32_t *d_nlong = nullptr;    // [nblocks] rows with spare accumulators (-1: the bin adds with LDS atomics)
+    int64_t bm_entries = 0;        // entries of the bin-major arrays
 };
 
 // SPMV_XSKIP (kernels_xskip.hip): the matrix in input-major segments per block of 1024 outputs
@@ -239,7 +248,7 @@ int launch_colsort(const spmv_csr &h, const PanelPlan &p, const float *x, float 
 void destroy_colsort(PanelPlan &p);
 // kernels_binned.hip: SPMV_PANEL mode 4
 int panel_tile_ptr(const spmv_csr &h, const int32_t *d_brow, int nblocks, int pw_bits, int np, int32_t *d_tile_ptr, hipStream_t s);
-int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, hipStream_t s);
+int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, bool scatter, hipStream_t s);
 int launch_binned(const spmv_csr &h, const PanelPlan &p, const float *x, float *y, hipStream_t s);
 void destroy_binned(PanelPlan &p);
 double binned_tile_nonzeros(const spmv_csr &h, int bin_rows);

@@ -15,12 +15,13 @@ from _util import DeviceProblem, assert_close_to_oracle, synth_problem
 pytestmark = pytest.mark.gpu
 
 
-def _params(capi, rows=0):
-    """params[6] = 4: binned; params[4] = rows per bin (0 = the library's rule | 4096 | 8192)."""
-    return [capi.PANEL, 0, 0, 0, rows, 0, 4, 0]
+def _params(capi, rows=0, mode=4):
+    """params[6] = 4: binned, 5: binned with the products stored in bin order; params[4] = rows per bin (0 = the library's
+    rule | 4096 | 8192)."""
+    return [capi.PANEL, 0, 0, 0, rows, 0, mode, 0]
 
 
-def _run(prob, capi, rows=0, wide=None):
+def _run(prob, capi, rows=0, wide=None, mode=4):
     """wide: None = the plan's rule (four products per lane where a tile holds a hundred or more, else one), True / False =
     forced (SPMV_BINNED_WIDE, read when the plan is made)."""
     import os
@@ -28,7 +29,7 @@ def _run(prob, capi, rows=0, wide=None):
     if wide is not None:
         os.environ["SPMV_BINNED_WIDE"] = "1" if wide else "0"
     try:
-        prob.A.plan_set(capi.PANEL, _params(capi, rows))
+        prob.A.plan_set(capi.PANEL, _params(capi, rows, mode))
     finally:
         os.environ.pop("SPMV_BINNED_WIDE", None)
     prob.d_y.fill_(float("nan"))
@@ -236,3 +237,124 @@ def test_auto_resolves_to_binned_where_x_is_beyond_the_caches(pkg, oracle, gpu):
     y64, mag = oracle.spmv_f64(rps, d_ci[k0:k1].cpu().numpy(), d_va[k0:k1].cpu().numpy(), d_x.cpu().numpy())
     assert_close_to_oracle(d_y[r0:r0 + n].cpu().numpy(), y64, mag, "auto -> binned, c3 uniform")
     A.close()
+
+
+# ---- the scattered flavour (params[6] = 5): the product launch stores in bin order, the sum launch streams accumulator numbers
+@pytest.mark.parametrize("bin_rows", [0, 4096, 8192])
+@pytest.mark.parametrize("name,band,scale", [("c2", 0, 1 / 4), ("c2", 8192, 1 / 8), ("c4", 0, 1 / 16), ("c4", 1000000, 1 / 16),
+                                             ("c4", 8192, 1 / 64), ("c3", 0, 1 / 16), ("c3", 8192, 1 / 64), ("c2", 0, 1.0)])
+def test_scattered_on_the_synthetic_laws(pkg, oracle, gpu, name, band, scale, bin_rows):
+    import torch
+    capi = pkg.capi
+    w = pkg.workloads.config(name, band=band, scale=scale)
+    prob = synth_problem(pkg, oracle, gpu, w)
+    y = _run(prob, capi, bin_rows, mode=5)
+    assert not np.isnan(y).any(), "rows left unwritten"
+    y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+    assert_close_to_oracle(y, y64, mag, f"binned, scattered products: {name} band {band}")
+    d = prob.A.plan_describe(capi.PANEL)
+    assert d.startswith("binned scattered_products bins="), d
+    got = prob.A.plan_params(capi.PANEL)
+    assert got[6] == 5 and got[4] in (4096, 8192)
+    if bin_rows:
+        assert got[4] == bin_rows
+    B = capi.CsrMatrix.from_device(prob.rows, prob.cols, prob.d_rp, prob.d_ci, prob.d_va)
+    B.plan_set(capi.PANEL, got)
+    assert B.plan_describe(capi.PANEL) == d
+    yb = torch.full((prob.rows,), float("nan"), device=gpu)
+    B.run(capi.PANEL, prob.d_x, yb)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.view(np.uint32), yb.cpu().numpy().view(np.uint32))
+    y2 = torch.full((prob.rows,), float("nan"), device=gpu)
+    prob.A.run(capi.PANEL, prob.d_x, y2)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.view(np.uint32), y2.cpu().numpy().view(np.uint32))
+    B.close(); prob.A.close()
+
+
+def test_scattered_on_golden_fixtures(pkg, oracle, gpu, golden):
+    """Dense-ish: one panel, every row many times in every step -- spare accumulators for every row, or the flagged bin's atomics."""
+    prob = DeviceProblem(pkg, gpu, golden.N, golden.M, golden.row_ptr, golden.col_idx, golden.vals, golden.x)
+    y64, mag = oracle.spmv_f64(golden.row_ptr, golden.col_idx, golden.vals, golden.x)
+    for rows in (4096, 8192):
+        y = _run(prob, pkg.capi, rows, mode=5)
+        assert_close_to_oracle(y, y64, mag, f"binned scattered/{golden.name}/{rows}")
+    prob.A.close()
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(runs=st.lists(row_run, min_size=1, max_size=5), cols=st.sampled_from([1, 7, 4096, 32767, 32768, 32769, 70_001, 1 << 19]),
+       dups=st.booleans(), seed=st.integers(0, 2**31 - 1))
+def test_scattered_random_structures(pkg, oracle, gpu, runs, cols, dups, seed):
+    """The structures of test_binned_random_structures: single huge rows fill whole steps with one row (63 spare accumulators),
+    many medium rows overflow the spare accumulators of a bin (flagged: LDS atomics)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lengths = []
+    for kind, length, count in runs:
+        if kind == "ragged":
+            lengths += list(rng.integers(0, length + 1, size=count))
+        else:
+            lengths += [length] * count
+    lengths = np.asarray(lengths, np.int64)
+    if lengths.sum() > 2_000_000:
+        lengths = lengths[: max(1, len(lengths) // 4)]
+    rp = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    ci = rng.integers(0, cols, size=int(rp[-1])).astype(np.int32)      # unsorted, duplicates possible
+    if not dups:
+        for r in range(len(lengths)):
+            ci[rp[r]:rp[r + 1]].sort()
+    va = rng.uniform(-1, 1, size=int(rp[-1])).astype(np.float32)
+    x = rng.uniform(-1, 1, size=cols).astype(np.float32)
+    prob = DeviceProblem(pkg, gpu, len(lengths), cols, rp, ci, va, x)
+    y = _run(prob, pkg.capi, [0, 4096, 8192][seed % 3], mode=5)
+    assert not np.isnan(y).any(), "rows left unwritten"
+    y64, mag = oracle.spmv_f64(rp, ci, va, x)
+    assert_close_to_oracle(y, y64, mag, "binned, scattered products")
+    prob.A.close()
+
+
+def test_scattered_edge_shapes_inf_nan_and_stale_values(pkg, oracle, gpu):
+    import torch
+    capi = pkg.capi
+    cases = [
+        (0, 5, np.zeros(1, np.int32), np.zeros(0, np.int32)),
+        (3, 5, np.zeros(4, np.int32), np.zeros(0, np.int32)),
+        (3, 5, np.array([0, 0, 1, 1], np.int32), np.array([4], np.int32)),
+        (1, 6000, np.array([0, 5000], np.int32), np.arange(5000, dtype=np.int32)),
+    ]
+    for rows, cols, rp, ci in cases:
+        va = np.linspace(-1, 1, len(ci), dtype=np.float32) if len(ci) else np.zeros(0, np.float32)
+        x = np.linspace(1, 2, cols, dtype=np.float32)
+        prob = DeviceProblem(pkg, gpu, rows, cols, rp, ci, va, x)
+        y = _run(prob, capi, mode=5)
+        if rows:
+            y64, mag = oracle.spmv_f64(rp, ci, va, x)
+            assert_close_to_oracle(y, y64, mag, f"binned scattered {rows}x{cols}")
+        prob.A.close()
+    rows, cols = 5000, 90000
+    rng = np.random.default_rng(7)
+    lengths = rng.integers(0, 20, size=rows)
+    rp = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(cols, size=int(L), replace=False)) for L in lengths]).astype(np.int32)
+    va = rng.uniform(-1, 1, size=len(ci)).astype(np.float32)
+    x = rng.uniform(-1, 1, size=cols).astype(np.float32)
+    x[0] = np.inf; x[40000] = np.nan; x[89999] = -np.inf
+    prob = DeviceProblem(pkg, gpu, rows, cols, rp, ci, va, x)
+    y = _run(prob, capi, mode=5)
+    y_seq = oracle.spmv(rp, ci, va, x)
+    assert np.array_equal(np.isnan(y), np.isnan(y_seq))
+    assert np.array_equal(np.isinf(y), np.isinf(y_seq)) and np.array_equal(y[np.isinf(y)], y_seq[np.isinf(y_seq)])
+    prob.d_va.mul_(2.0)
+    prob.A.values_changed()
+    with pytest.raises(capi.SpmvError) as ei:
+        prob.A.run(capi.PANEL, prob.d_x, prob.d_y)
+    assert ei.value.status == capi.ERR_STALE_PLAN
+    prob.A.plan(capi.PANEL)
+    assert prob.A.plan_describe(capi.PANEL).startswith("binned scattered_products bins=")
+    x2 = np.where(np.isfinite(x), x, 0.5).astype(np.float32)
+    prob.d_x.copy_(torch.from_numpy(x2))
+    prob.A.run(capi.PANEL, prob.d_x, prob.d_y)
+    torch.cuda.synchronize()
+    y64, mag = oracle.spmv_f64(rp, ci, 2.0 * va, x2)
+    assert_close_to_oracle(prob.d_y[:rows].cpu().numpy(), y64, mag, "binned scattered after re-plan")
+    prob.A.close()

@@ -123,20 +123,25 @@ def test_all_variants_agree_on_every_row(c4, pkg):
         assert bad == 0, f"{name}: {bad} rows differ from scalar beyond {RTOL}*sum|terms|"
 
 
-def test_binned_layout_forced_at_full_size(c4, pkg):
-    """The binned layout of the panel family (round 4) forced on the uniform-column fixtures -- config 4 (512 panels, 83
-    nonzeros per tile: what SPMV_AUTO takes) and config 5's shards (4096 panels of 32768 columns = the layout's limit, ten
-    nonzeros per tile: where AUTO keeps the sweep) -- against SCALAR (bit-identical to the oracle wherever sampled) on every
-    row, and again on a second handle planned with the reported numbers (bit-identical)."""
+@pytest.mark.parametrize("mode", [4, 5])
+def test_binned_layout_forced_at_full_size(c4, pkg, mode):
+    """The binned layouts of the panel family (round 4) forced on the uniform-column fixtures -- config 4 (512 panels, 83
+    nonzeros per tile: SPMV_AUTO takes mode 4, the sum launch fetches the tiles) and config 5's shards (4096 panels of 32768
+    columns = the layout's limit, 14-28 nonzeros per tile: AUTO takes mode 5, the product launch stores in bin order) -- each
+    mode on both, against SCALAR (bit-identical to the oracle wherever sampled) on every row, and again on the same handle
+    (bit-identical: both launches are deterministic)."""
     import torch
     if c4["w"].band != 0:
         pytest.skip("uniform columns only (the banded fixtures' tiles are a few fat ones per bin: covered at small scale)")
     capi = pkg.capi
     ref = _run(c4, pkg, capi.SCALAR)
     B = capi.CsrMatrix.from_device(c4["n"], c4["w"].cols, c4["d_rp"], c4["d_ci"], c4["d_va"])
-    B.plan_set(capi.PANEL, [capi.PANEL, 0, 0, 0, 0, 0, 4, 0])
+    B.plan_set(capi.PANEL, [capi.PANEL, 0, 0, 0, 0, 0, mode, 0])
     d = B.plan_describe(capi.PANEL)
-    assert d.startswith("binned bins=") and "flagged_tiles=0 " in d, d
+    if mode == 4:
+        assert d.startswith("binned bins=") and "flagged_tiles=0 " in d, d
+    else:
+        assert d.startswith("binned scattered_products bins=") and "flagged_bins=0 " in d, d
     y = torch.full((c4["n"],), float("nan"), device=c4["d_x"].device)
     B.run(capi.PANEL, c4["d_x"], y)
     torch.cuda.synchronize()
@@ -152,15 +157,15 @@ def test_binned_layout_forced_at_full_size(c4, pkg):
 
 def test_auto_choice_at_full_size(c4, pkg):
     """SPMV_AUTO at the BASELINE sizes: the LDS-tiled kernel on a band of 8192 columns; on uniform columns the binned layout
-    of the panel family (round 4: two streaming launches) where a (bin, panel) tile still holds dozens of nonzeros -- config
-    4 -- and the panel sweep where it holds ten -- config 5's shard, 128Mi columns; the sorted blocks of the panel family on
-    a band of 1M columns (65 536: whichever the models price lower)."""
+    of the panel family (round 4: two streaming launches) -- the sum launch fetching the tiles where a (bin, panel) tile
+    holds dozens of nonzeros, config 4; the product launch storing in bin order where it holds 14-28, config 5's shard,
+    128Mi columns; the sorted blocks of the panel family on a band of 1M columns (65 536: whichever the models price lower)."""
     d = c4["A"].plan_describe(pkg.capi.AUTO)
     band = c4["w"].band
     if band == 0 and c4["w"].cols == c4["w"].rows and c4["A"].rows == c4["w"].rows:
         assert d.startswith("auto -> panel: binned bins="), d
     elif band == 0:
-        assert d.startswith("auto -> panel: panel_columns="), d
+        assert d.startswith("auto -> panel: binned scattered_products bins="), d
     elif band <= 8192:
         assert d.startswith("auto -> tiled"), d
     elif band >= 1_000_000:

@@ -73,7 +73,7 @@ def main():
                       "hbm_bytes_per_launch": int(round((read_factor * f_kib + write_factor * w_kib) * 1024))}
     # the plan autotunes over several instantiations of k_adaptive: the timed one has the most launches
     binned = variant == "panel" and "binned" in plan
-    hot = (("k_bin_products",) if binned else ("k_panel(", "k_colsort") if variant == "panel" else
+    hot = (("k_bin_products", "k_bs_products") if binned else ("k_panel(", "k_colsort") if variant == "panel" else
            ("k_wave_bundle",) if variant in ("wave_pipe", "scalar", "wave") else
            ("k_adaptive", "k_tiled16", "k_tiled_mixed", "k_sorted"))
     dom = max((k for k in kernels if any(h in k for h in hot)), key=lambda k: kernels[k]["launches"])
@@ -85,10 +85,10 @@ def main():
         kernels[dom]["note"] = "counters of k_wave_bundle + k_wave_pieces + k_wave_combine: one SpMV"
     if binned:                      # one SpMV = the product launch + the sum launch
         for k in kernels:
-            if k != dom and "k_bin_sums" in k:
+            if k != dom and ("k_bin_sums" in k or "k_bs_sums" in k):
                 for key in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_per_launch"):
                     kernels[dom][key] = kernels[dom][key] + kernels[k][key]
-        kernels[dom]["note"] = "counters of k_bin_products + k_bin_sums: one SpMV"
+        kernels[dom]["note"] = "counters of the product launch + the sum launch: one SpMV"
     # the panel sweep covers the matrix in several launches of the same kernel ("launches=N" in the plan string):
     # scale the per-launch counters to one SpMV so they compare with the algorithmic bytes of one SpMV
     per_spmv = 1
