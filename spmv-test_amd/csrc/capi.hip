@@ -546,9 +546,9 @@ int64_t spmv_csr_plan_bytes(const spmv_csr_t *h, int variant)
             return (int64_t)h->plan_xskip.nseg * 8 + ((int64_t)h->plan_xskip.nblocks + 1) * 4 +
                    (h->plan_xskip.slabs > 1 ? (int64_t)h->plan_xskip.nblocks * h->plan_xskip.slabs * 1024 * 8 : 0);
         case SPMV_PANEL:     // tile_ptr; packed/pvals REPLACE col_idx/vals byte for byte (sorted blocks: + the empty slots)
-            if (panel.binned_mode && panel.scatter_mode)   // panel-major: column 2 + value 4 + destination 4; bin-major: product 4 + accumulator 2; the lists
-                return panel.padded * (2 + 4 + 4) + panel.bm_entries * (4 + 2) + (int64_t)panel.nblocks * (2048 * 4 + 16) +
-                       ((int64_t)panel.npanels + 1) * 4;
+            if (panel.binned_mode && panel.scatter_mode)   // panel-major: column 2 + value 4, an offset per run; bin-major: product 4 + accumulator 2; the lists
+                return panel.padded * (2 + 4) + panel.padded / 512 * 4 + panel.runs * 4 + panel.bm_entries * (4 + 2) +
+                       (int64_t)panel.nblocks * (1024 * 4 + 16) + ((int64_t)panel.npanels + 1) * 4;
             if (panel.binned_mode)   // two tables per tile, 16-bit columns and rows, the products written and read back; pvals REPLACES vals
                 return (int64_t)panel.nblocks * (2 * (int64_t)panel.npanels + 2) * 4 + panel.padded * (2 + 4 + 4) + h->nnz * 2;
             if (panel.sorted_mode)   // unit bases, block tables, the rows of the tail units, the empty slots of the units in use

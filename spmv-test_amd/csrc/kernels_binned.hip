@@ -193,18 +193,20 @@ __global__ __launch_bounds__(kProdThreads) void k_bin_products(int splits, int64
 // The flavour above lets the sum launch FETCH tile (b, p) from the panel-major products: a piece of <= 64 E products of one
 // tile per instruction group.  That is as good as the tiles are fat -- config 5's shard has 10-20 products per tile, so
 // nine lanes in ten idle and every tile costs its table entries (4.1 ms against the sweep's 3.0).  Here the PRODUCT launch
-// carries the permutation instead: it streams the panel-major entries (16-bit column, value, and the entry's bin-major
-// position: 10 B) and stores each product at that position -- a tile stays one contiguous run in both orders, and the
-// panel-major arrays are interleaved in blocks of 512 so that the 64 lanes of one store hold 64 CONSECUTIVE entries
-// (16-byte loads per lane AND whole runs per store).  The sum launch is then a pure stream per bin: 4 B of product + a
+// carries the permutation instead: it streams the panel-major entries (15-bit column + a "first of its tile" bit, value:
+// 6 B) and stores each product at its bin-major position -- a tile is one contiguous RUN in both orders, so the position is
+// the entry's own index plus its run's offset (4 B per run: run number = the block's first run + the flags counted up to
+// the entry, a ballot per store), and the panel-major arrays are interleaved in blocks of 512 so that the 64 lanes of one
+// store hold 64 CONSECUTIVE entries (16-byte loads per lane AND whole runs per store).  The sum launch is then a pure stream per bin: 4 B of product + a
 // 16-bit ACCUMULATOR index, 256 entries per piece (four consecutive per lane), no tile table at all.  What keeps the
 // read-add-write of a step free of collisions is decided when the plan is made: entry k of every lane forms a step; the
 // j-th entry of a step that names a row already named in it gets the row's j-th spare accumulator (k_bs_accs), the spare
 // accumulators join the row's own at the end of the bin.  A bin that needs more spare accumulators than there are (kPool) is
 // flagged and adds with LDS atomics.
 constexpr int kBlk = 512;                  // interleave block of the panel-major arrays: lane l of a wavefront holds entries l, 64 + l, ...
-constexpr int kPool = 2048;                // spare accumulators of a bin
+constexpr int kPool = 1024;                // spare accumulators of a bin (8192 + 1024 + 64 words: four wavefronts per CU)
 constexpr int kBmPiece = 256;              // entries of the bin-major arrays per wavefront instruction group
+constexpr int kRunBit = 1 << kPwBits;      // bit 15 of a panel-major column: this entry is the first of its run
 
 __device__ __forceinline__ int interleaved(int q) { return (q & ~(kBlk - 1)) | ((q & 63) << 3) | ((q >> 6) & 7); }
 
@@ -219,13 +221,85 @@ __global__ void k_bs_counts(int nb, int np, const int32_t *__restrict__ tile_ptr
     bbase[b] = (n + kBmPiece - 1) & ~(kBmPiece - 1);
 }
 
+
+// Runs of the panel-major order: the nonempty tiles of a panel, bins ascending, then the panel's pad slots (one run slot per
+// panel whether it has pad slots or not).  nruns[p] = the panel's run slots (scanned afterwards: first run of every panel).
+__global__ __launch_bounds__(256) void k_bs_nruns(int nb, int np, const int32_t *__restrict__ tile_ptr, int32_t *__restrict__ nruns)
+{
+    __shared__ int part[256];
+    const int p = blockIdx.x;
+    int sum = 0;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+        sum += tp[p + 1] > tp[p] ? 1 : 0;
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nruns[p] = part[0] + 1;
+}
+// offset[run] = bin-major position - panel-major position of the run's entries; first_run[block of 512] = the run of the
+// block's first entry (minus one where that entry starts a run: the product launch counts the flags INCLUSIVELY).  The pad
+// slots of a panel are a run that lands behind the last bin (entries bm .. bm + 511: nothing reads them); its first slot
+// gets the flag here (the fill kernel writes real entries only).  One workgroup per panel, bins scanned 256 at a time.
+__global__ __launch_bounds__(256) void k_bs_runs(int nb, int np, int32_t bm, const int32_t *__restrict__ tile_ptr,
+                                                 const int32_t *__restrict__ pm, const int32_t *__restrict__ pbase,
+                                                 const int32_t *__restrict__ bbase, const int32_t *__restrict__ run0,
+                                                 int32_t *__restrict__ offset, int32_t *__restrict__ first_run, uint16_t *__restrict__ c16)
+{
+    __shared__ int part[256];
+    __shared__ int carry, last_end;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) { carry = 0; last_end = pbase[p]; }
+    __syncthreads();
+    const int r0 = run0[p];
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int b = b0 + tid;
+        int c = 0, q0 = 0, d0 = 0;
+        if (b < nb) {
+            const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+            c = tp[p + 1] - tp[p];
+            q0 = pm[(int64_t)b * np + p];
+            d0 = bbase[b] + (tp[p] - tp[0]);
+        }
+        part[tid] = c > 0 ? 1 : 0;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (c > 0) {
+            const int t = r0 + carry + part[tid] - 1;
+            offset[t] = d0 - q0;
+            for (int q = (q0 + kBlk - 1) & ~(kBlk - 1); q < q0 + c; q += kBlk) first_run[q / kBlk] = t - (q == q0 ? 1 : 0);
+            atomicMax(&last_end, q0 + c);
+        }
+        __syncthreads();
+        if (tid == 255) carry += part[255];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int q0 = last_end, q1 = pbase[p + 1];                 // the pad slots
+        if (q0 < q1) {
+            const int t = r0 + carry;
+            offset[t] = bm - q0;
+            c16[interleaved(q0)] = (uint16_t)kRunBit;
+            for (int q = (q0 + kBlk - 1) & ~(kBlk - 1); q < q1; q += kBlk) first_run[q / kBlk] = t - (q == q0 ? 1 : 0);
+        }
+    }
+}
+
 // k_bin_fill for this flavour: rows at the bin-major (padded) position, the panel-major entry interleaved, and its destination
 __global__ __launch_bounds__(256) void k_bs_fill(int nb, int np, const int32_t *__restrict__ brow, const int32_t *__restrict__ row_ptr,
                                                  const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
                                                  const uint16_t *__restrict__ rowloc, const int32_t *__restrict__ tile_ptr,
                                                  const int32_t *__restrict__ pm, const int32_t *__restrict__ bbase,
-                                                 uint16_t *__restrict__ c16, float *__restrict__ pvals, int32_t *__restrict__ dst,
-                                                 uint16_t *__restrict__ acc)
+                                                 uint16_t *__restrict__ c16, float *__restrict__ pvals, uint16_t *__restrict__ acc)
 {
     extern __shared__ int cursor_all[];     // 4 x np
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
@@ -263,17 +337,18 @@ __global__ __launch_bounds__(256) void k_bs_fill(int nb, int np, const int32_t *
         if (valid) {
             acc[dest + shift] = (uint16_t)rl;                  // (k_bs_accs turns rows into accumulators)
             const int q = interleaved(qp[p] + (dest - tp[p]));
-            c16[q] = (uint16_t)(col & (kPw - 1));
+            c16[q] = (uint16_t)((col & (kPw - 1)) | (dest == tp[p] ? kRunBit : 0));   // the first entry of its tile starts a run
             pvals[q] = v;
-            dst[q] = dest + shift;
         }
     }
 }
 
-// Accumulators of one bin (a wavefront per bin).  Step (piece, k) of the sum launch holds entries piece * 256 + 4 l + k of the
-// bin, l = 0..63.  occ = how many lower lanes of the step name the same row.  Pass A: the deepest occ of every row; then the
-// spare accumulators are dealt out (occ of them per row) and the bin's list written; pass B: entry -> row (occ 0) or the
-// row's spare accumulator number occ - 1.  LDS: tag[RB] (who wrote last) and deep[RB] (max occ, then the first spare).
+// Accumulators of one bin (a wavefront per bin).  A STEP of the sum launch holds 128 entries of the bin: entries 4 l + 2 h and
+// 4 l + 2 h + 1 of piece (256 entries), l = 0..63, h = 0 | 1 -- the launch reads the 128 accumulators, adds, writes them back,
+// so no accumulator may be named twice in a step.  occ = how many entries before this one in its step (first entries of the
+// lanes, then second entries, lanes ascending) name the same row.  Pass A: the deepest occ of every row; then the spare
+// accumulators are dealt out (occ of them per row) and the bin's list written; pass B: entry -> row (occ 0) or the row's spare
+// accumulator number occ - 1.  LDS: tag[RB] (who wrote last) and deep[RB] (max occ, then the first spare).
 template <int RB>
 __global__ __launch_bounds__(kWave) void k_bs_accs(const int32_t *__restrict__ brow, const int32_t *__restrict__ bbase,
                                                    const int32_t *__restrict__ bcnt, uint16_t *__restrict__ acc,
@@ -287,8 +362,8 @@ __global__ __launch_bounds__(kWave) void k_bs_accs(const int32_t *__restrict__ b
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int i = lane; i < RB; i += kWave) deep[i] = 0;
     __builtin_amdgcn_wave_barrier();
-    // occ of this lane's entry in its step
-    auto occurrence = [&](bool valid, int r) {
+    // lanes of one instruction: how many lower lanes name the same row
+    auto among = [&](bool valid, int r) {
         if (valid) reinterpret_cast<volatile int *>(tag)[r] = lane;
         __builtin_amdgcn_wave_barrier();
         const int wtag = valid ? reinterpret_cast<volatile int *>(tag)[r] : lane;
@@ -303,22 +378,51 @@ __global__ __launch_bounds__(kWave) void k_bs_accs(const int32_t *__restrict__ b
         }
         return occ;
     };
+    // the two entries of a lane in one step: occ of both (the second ones count every first one of their row)
+    auto occurrences = [&](bool v0, int r0, bool v1, int r1, int &occ0, int &occ1) {
+        occ0 = among(v0, r0);                                       // (tag[r0] = some lane whose first entry names r0)
+        __builtin_amdgcn_wave_barrier();
+        const int t = v1 ? reinterpret_cast<volatile int *>(tag)[r1] & (kWave - 1) : 0;   // stale or never written: checked next
+        const int rt = __shfl(v0 ? r0 : -1, t);                     // (every lane takes part: the lane asked may have no second entry)
+        const bool cross = v1 && rt == r1;                          // a first entry of this step names my row
+        int firsts = 0;
+        unsigned long long todo = __ballot(cross);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int rl = __shfl(r1, leader);
+            const int c = __popcll(__ballot(v0 && r0 == rl));
+            const unsigned long long m = __ballot(v1 && r1 == rl);
+            if (v1 && r1 == rl) firsts = c;
+            todo &= ~m;
+        }
+        __builtin_amdgcn_wave_barrier();
+        occ1 = firsts + among(v1, r1);
+    };
+    auto entry = [&](int e0, int h, int j, bool &valid, int &r) {
+        const int i = e0 + 4 * lane + 2 * h + j;
+        valid = i < n;
+        r = valid ? (int)acc[base + i] : 0;
+        return base + i;
+    };
     int deepest = 0;
     for (int e0 = 0; e0 < n; e0 += kBmPiece)
-        for (int k = 0; k < 4; ++k) {
-            const int i = e0 + 4 * lane + k;
-            const bool valid = i < n;
-            const int r = valid ? (int)acc[base + i] : 0;
-            const int occ = occurrence(valid, r);
-            if (occ > 0) atomicMax(&deep[r], occ);
-            deepest = occ > deepest ? occ : deepest;
+        for (int h = 0; h < 2; ++h) {
+            bool v0, v1;
+            int r0, r1, occ0, occ1;
+            entry(e0, h, 0, v0, r0);
+            entry(e0, h, 1, v1, r1);
+            occurrences(v0, r0, v1, r1, occ0, occ1);
+            if (occ0 > 0) atomicMax(&deep[r0], occ0);
+            if (occ1 > 0) atomicMax(&deep[r1], occ1);
+            deepest = occ0 > deepest ? occ0 : deepest;
+            deepest = occ1 > deepest ? occ1 : deepest;
         }
     if (__ballot(deepest > 0) == 0ull) {                            // no row twice in any step
         if (lane == 0) nlong[b] = 0;
         return;
     }
     __builtin_amdgcn_wave_barrier();
-    // the spare accumulators, rows ascending; the list: row << 17 | first << 6 | count
+    // the spare accumulators, rows ascending; the list: row << 17 | first << 7 | count (at most 127)
     int used = 0, listed = 0;
     bool over = false;
     for (int r0 = 0; r0 < nrows && !over; r0 += kWave) {
@@ -336,7 +440,7 @@ __global__ __launch_bounds__(kWave) void k_bs_accs(const int32_t *__restrict__ b
         const unsigned long long lm = __ballot(need > 0);
         if (need > 0) {
             deep[r] = first;
-            lrow[(int64_t)b * kPool + listed + __popcll(lm & lt)] = ((uint32_t)r << 17) | ((uint32_t)first << 6) | (uint32_t)need;
+            lrow[(int64_t)b * kPool + listed + __popcll(lm & lt)] = ((uint32_t)r << 17) | ((uint32_t)first << 7) | (uint32_t)need;
         }
         used += total;
         listed += __popcll(lm);
@@ -348,25 +452,38 @@ __global__ __launch_bounds__(kWave) void k_bs_accs(const int32_t *__restrict__ b
     if (lane == 0) { nlong[b] = listed; atomicAdd(&stats[1], listed); }
     __builtin_amdgcn_wave_barrier();
     for (int e0 = 0; e0 < n; e0 += kBmPiece)
-        for (int k = 0; k < 4; ++k) {
-            const int i = e0 + 4 * lane + k;
-            const bool valid = i < n;
-            const int r = valid ? (int)acc[base + i] : 0;
-            const int occ = occurrence(valid, r);
-            if (occ > 0) acc[base + i] = (uint16_t)(RB + deep[r] + occ - 1);
+        for (int h = 0; h < 2; ++h) {
+            bool v0, v1;
+            int r0, r1, occ0, occ1;
+            const int i0 = entry(e0, h, 0, v0, r0);
+            const int i1 = entry(e0, h, 1, v1, r1);
+            occurrences(v0, r0, v1, r1, occ0, occ1);
+            if (occ0 > 0) acc[i0] = (uint16_t)(RB + deep[r0] + occ0 - 1);
+            if (occ1 > 0) acc[i1] = (uint16_t)(RB + deep[r1] + occ1 - 1);
         }
 }
 
 // launch 1 of this flavour: products in panel order, stored in bin order
-__global__ __launch_bounds__(kProdThreads) void k_bs_products(int splits, int64_t cols, const int32_t *__restrict__ pbase,
+__global__ __launch_bounds__(kProdThreads) void k_bs_products(int splits, int np, int64_t cols, const int32_t *__restrict__ pbase,
                                                               const uint16_t *__restrict__ c16, const float *__restrict__ pvals,
-                                                              const int32_t *__restrict__ dst, const float *__restrict__ x,
-                                                              float *__restrict__ prod)
+                                                              const int32_t *__restrict__ first_run, const int32_t *__restrict__ offset,
+                                                              const float *__restrict__ x, float *__restrict__ prod)
 {
     extern __shared__ __attribute__((aligned(16))) float xp[];      // the panel: kPw floats
-    using i4 = int __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x;
-    const int p = blockIdx.x / splits, part = blockIdx.x - p * splits;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    int p = blockIdx.x / splits;
+    const int part = blockIdx.x - p * splits;
+#ifndef SPMV_BS_AB_NOXCD
+    if (splits == 1) {
+        // Workgroups go round the eight XCDs; an XCD takes a contiguous EIGHTH of the panels.  Tiles (b, p) and (b, p + 1) are
+        // neighbours in the bin-major products and share a 128-byte line: written through ONE L2 a few microseconds apart the
+        // line leaves it whole; written through two, each L2 writes its part back under a byte mask
+        // (config 5's shard: 1.63 -> 1.36 ms, profiles/r04_scattered_products_xcd.jsonl)
+        const int per8 = (np + 7) >> 3;
+        p = (int)(blockIdx.x & 7u) * per8 + (int)(blockIdx.x >> 3);
+        if (p >= np) return;                                        // (the grid is 8 per8 workgroups)
+    }
+#endif
     const int64_t g0 = (int64_t)p << kPwBits;
     if (g0 + kPw + 3 < cols) {                                      // workgroup-uniform
 #pragma unroll
@@ -381,28 +498,32 @@ __global__ __launch_bounds__(kProdThreads) void k_bs_products(int splits, int64_
     if (b > b0) b = b0;
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): this wave's pieces of the panel have landed
     __syncthreads();
+    const unsigned long long le = (2ull << lane) - 1ull;            // this lane and the ones below
 #ifdef SPMV_BS_AB_NOSTORE
     float keep = 0.0f;
 #endif
     for (int k = a + tid * 8; k < b; k += kProdThreads * 8) {       // a wavefront: one interleave block per trip
+        const int blk = __builtin_amdgcn_readfirstlane(k >> 9);
+        const int t0 = first_run[blk];
         const u4 c = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(c16 + k));
         const f4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(pvals + k));
         const f4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(pvals + k + 4));
-        const i4 d0 = __builtin_nontemporal_load(reinterpret_cast<const i4 *>(dst + k));
-        const i4 d1 = __builtin_nontemporal_load(reinterpret_cast<const i4 *>(dst + k + 4));
+        const unsigned cw[8] = {c.x & 0xffffu, c.x >> 16, c.y & 0xffffu, c.y >> 16, c.z & 0xffffu, c.z >> 16, c.w & 0xffffu, c.w >> 16};
+        const float vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        int run = t0;                                               // (scalar) runs begun before store j's entries, from t0
+        const int q = (k & ~(kBlk - 1)) + lane;                     // entry of store 0; store j: q + 64 j
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                               // store j of the 64 lanes: 64 consecutive entries of the panel
+            const unsigned long long starts = __ballot((cw[j] & (unsigned)kRunBit) != 0u);
+            const int d = offset[run + __popcll(starts & le)];
+            run += __popcll(starts);
+            const float o = xp[cw[j] & (unsigned)(kPw - 1)] * vw[j];
 #ifdef SPMV_BS_AB_NOSTORE      // (A/B, wrong results: everything but the stores)
-        keep += xp[c.x & 0xffffu] * v0.x + xp[c.x >> 16] * v0.y + xp[c.y & 0xffffu] * v0.z + xp[c.y >> 16] * v0.w + xp[c.z & 0xffffu] * v1.x +
-                xp[c.z >> 16] * v1.y + xp[c.w & 0xffffu] * v1.z + xp[c.w >> 16] * v1.w + (float)(d0.x ^ d0.y ^ d0.z ^ d0.w ^ d1.x ^ d1.y ^ d1.z ^ d1.w);
+            keep += o + (float)d;
 #else
-        prod[d0.x] = xp[c.x & 0xffffu] * v0.x;                      // store j of the 64 lanes: 64 consecutive entries of the panel
-        prod[d0.y] = xp[c.x >> 16] * v0.y;
-        prod[d0.z] = xp[c.y & 0xffffu] * v0.z;
-        prod[d0.w] = xp[c.y >> 16] * v0.w;
-        prod[d1.x] = xp[c.z & 0xffffu] * v1.x;
-        prod[d1.y] = xp[c.z >> 16] * v1.y;
-        prod[d1.z] = xp[c.w & 0xffffu] * v1.z;
-        prod[d1.w] = xp[c.w >> 16] * v1.w;
+            prod[q + 64 * j + d] = o;
 #endif
+        }
     }
 #ifdef SPMV_BS_AB_NOSTORE
     prod[tid & 15] = keep;
@@ -436,9 +557,14 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
 #pragma unroll
         for (int u = 0; u < kD; ++u) {
             const unsigned at = (unsigned)base + (unsigned)(pi0 + u) * kBmPiece;
-#ifdef SPMV_BS_AB_NOLOAD       // (A/B, wrong results: the LDS side alone)
+#ifdef SPMV_BS_AB_NOLOAD       // (A/B, wrong results: the LDS side alone; 1 = random accumulators, 2 = one bank per lane)
             c.v[u] = u4v{at, at, at, at};
-            c.a[u] = u2v{(at * 2654435761u) & 0x0fff0fffu, (at * 40503u + lane * 977u) & 0x0fff0fffu};
+            {
+                unsigned h0 = (at + (unsigned)lane * 0x9E3779B1u) * 0x85EBCA6Bu, h1 = (h0 ^ (h0 >> 13)) * 0xC2B2AE35u;
+                h0 ^= h0 >> 16; h1 ^= h1 >> 15;
+                if (SPMV_BS_AB_NOLOAD == 2) { h0 = (h0 & 0x0fc00fc0u) | (unsigned)lane | ((unsigned)lane << 16) ^ 0x00200000u; h1 = (h1 & 0x0fc00fc0u) | (unsigned)lane | ((unsigned)lane << 16) ^ 0x00200000u; }
+                c.a[u] = u2v{h0 & 0x0fff0fffu, h1 & 0x0fff0fffu};
+            }
 #else
             c.v[u] = __builtin_amdgcn_raw_buffer_load_b128(pr, lane * 16, (int)(at * 4u), 0);
             c.a[u] = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, (int)(at * 2u), 0);
@@ -453,15 +579,21 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
         for (int u = 0; u < kD; ++u) {
             const bool live = pi0 + u < pieces;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                           // step k: no accumulator twice (k_bs_accs)
-                const unsigned w = c.a[u][k >> 1];
-                const int a = live ? (int)((k & 1) ? w >> 16 : w & 0xffffu) : kDummy;
-                const float v = __uint_as_float(c.v[u][k]);
+            for (int h = 0; h < 2; ++h) {                           // a step: two entries of every lane, 128 accumulators, none twice (k_bs_accs)
+                const unsigned w = c.a[u][h];
+                const int a0 = live ? (int)(w & 0xffffu) : kDummy, a1 = live ? (int)(w >> 16) : kDummy + 1;
+                const float v0 = __uint_as_float(c.v[u][2 * h]), v1 = __uint_as_float(c.v[u][2 * h + 1]);
 #ifdef SPMV_BS_AB_NOLDS        // (A/B, wrong results: the memory side alone)
-                sums[kDummy + (lane & 63)] = __uint_as_float(__float_as_uint(v) ^ (unsigned)a);
+                sums[kDummy + (lane & 63)] = __uint_as_float(__float_as_uint(v0) ^ __float_as_uint(v1) ^ (unsigned)(a0 + a1));
 #else
-                if (decltype(flagged)::value) atomicAdd(&sums[a], v);
-                else sums[a] += v;
+                if (decltype(flagged)::value) {
+                    atomicAdd(&sums[a0], v0);
+                    atomicAdd(&sums[a1], v1);
+                } else {
+                    const float s0 = sums[a0], s1 = sums[a1];       // both reads before either write: one LDS round trip per 128 entries
+                    sums[a0] = s0 + v0;
+                    sums[a1] = s1 + v1;
+                }
 #endif
             }
         }
@@ -484,11 +616,15 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
             issue(pi0 + 3 * kD, sb);
         }
     };
+#ifdef SPMV_BS_AB_ATOMIC       // (A/B: every bin through the LDS atomics; right results where no spare accumulators are in use)
+    stream(std::true_type());
+#else
     if (nl >= 0) stream(std::false_type());
     else stream(std::true_type());                                  // flagged bin (wave-uniform): LDS atomics
+#endif
     for (int i = lane; i < nl; i += kWave) {                        // the spare accumulators join their rows, in order
         const uint32_t w = lrow[(int64_t)b * kPool + i];
-        const int row = (int)(w >> 17), first = RB + (int)((w >> 6) & 0x7ffu), cnt = (int)(w & 63u);
+        const int row = (int)(w >> 17), first = RB + (int)((w >> 7) & 0x3ffu), cnt = (int)(w & 127u);
         float t = sums[row];
         for (int c = 0; c < cnt; ++c) t += sums[first + c];
         sums[row] = t;
@@ -783,11 +919,12 @@ void destroy_binned(PanelPlan &p)
     if (p.d_lptr) (void)hipFree(p.d_lptr);
     if (p.d_lrow) (void)hipFree(p.d_lrow);
     if (p.d_lcnt) (void)hipFree(p.d_lcnt);
-    if (p.d_dst) (void)hipFree(p.d_dst);
+    if (p.d_offset) (void)hipFree(p.d_offset);
+    if (p.d_first_run) (void)hipFree(p.d_first_run);
     if (p.d_bbase) (void)hipFree(p.d_bbase);
     if (p.d_bcnt) (void)hipFree(p.d_bcnt);
     if (p.d_nlong) (void)hipFree(p.d_nlong);
-    p.d_dst = p.d_bbase = p.d_bcnt = p.d_nlong = nullptr;
+    p.d_offset = p.d_first_run = p.d_bbase = p.d_bcnt = p.d_nlong = nullptr;
     p.scatter_mode = false;
     p.d_lptr = p.d_lcnt = nullptr;
     p.d_lrow = nullptr;
@@ -812,7 +949,7 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
 {
     const int nb = p.nblocks, np = p.npanels;
     int rc;
-    DevPtr<int32_t> bbase, bcnt, total, dst, nlong, stats;
+    DevPtr<int32_t> bbase, bcnt, total, nlong, stats, run0, offset, first_run;
     DevPtr<uint32_t> lrow;
     DevPtr<uint16_t> rowloc, c16, acc;
     DevPtr<float> pvals, prod;
@@ -830,19 +967,29 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
         set_error("spmv_csr_plan(panel, binned, scattered products): %d bins pad nnz %lld beyond 2^30 entries", nb, (long long)h.nnz);
         return SPMV_ERR_INVALID;
     }
-    const size_t nslot = (size_t)padded + 8, bslot = (size_t)bm + 16;       // (entry bm: where the pad slots of the panels store)
+    const size_t nslot = (size_t)padded + 8, bslot = (size_t)bm + kBlk + 16;       // (entries bm ...: where the pad slots of the panels store)
     SPMV_HIP_TRY(c16.alloc(nslot));
     SPMV_HIP_TRY(pvals.alloc(nslot));
-    SPMV_HIP_TRY(dst.alloc(nslot));
     SPMV_HIP_TRY(prod.alloc(bslot));
     SPMV_HIP_TRY(acc.alloc(bslot));
     SPMV_HIP_TRY(rowloc.alloc((size_t)h.nnz + 8));
     SPMV_HIP_TRY(nlong.alloc((size_t)nb));
     SPMV_HIP_TRY(lrow.alloc((size_t)nb * kPool));
     SPMV_HIP_TRY(stats.alloc(2));
+    // the runs of the panel-major order (nonempty tiles + one slot per panel for its pad slots)
+    SPMV_HIP_TRY(run0.alloc((size_t)np + 1));
+    k_bs_nruns<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, tiles.p, run0.p);
+    if ((rc = check("k_bs_nruns"))) return rc;
+    if ((rc = exclusive_scan_i32(run0.p, np, total.p, s))) return rc;
+    int32_t nruns = 0;
+    SPMV_HIP_TRY(hipMemcpyAsync(&nruns, total.p, sizeof nruns, hipMemcpyDeviceToHost, s));
+    SPMV_HIP_TRY(hipStreamSynchronize(s));
+    SPMV_HIP_TRY(offset.alloc((size_t)nruns + 1));
+    SPMV_HIP_TRY(first_run.alloc((size_t)padded / kBlk + 1));
+    SPMV_HIP_TRY(hipMemsetAsync(offset.p, 0, sizeof(int32_t) * ((size_t)nruns + 1), s));
+    SPMV_HIP_TRY(hipMemsetAsync(first_run.p, 0, sizeof(int32_t) * ((size_t)padded / kBlk + 1), s));
     SPMV_HIP_TRY(hipMemsetAsync(c16.p, 0, sizeof(uint16_t) * nslot, s));     // the pad slots of every panel: column 0, value 0 ...
     SPMV_HIP_TRY(hipMemsetAsync(pvals.p, 0, sizeof(float) * nslot, s));
-    SPMV_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dst.p), bm, nslot, s));   // ... stored where nothing reads
     SPMV_HIP_TRY(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(acc.p), (unsigned short)(rb + kPool), bslot, s));   // pad entries: the dummy word
     SPMV_HIP_TRY(hipMemsetAsync(prod.p, 0, sizeof(float) * bslot, s));
     SPMV_HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(int32_t) * 2, s));
@@ -850,8 +997,10 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
     if (h.nnz > 0) {
         if ((rc = panel_rowloc(h, brow.p, nb, rowloc.p, s))) return rc;
         k_bs_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), sizeof(int) * 4 * (size_t)np, s>>>(
-            nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, tiles.p, pm.p, bbase.p, c16.p, pvals.p, dst.p, acc.p);
+            nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, tiles.p, pm.p, bbase.p, c16.p, pvals.p, acc.p);
         if ((rc = check("k_bs_fill"))) return rc;
+        k_bs_runs<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, bm, tiles.p, pm.p, pbase.p, bbase.p, run0.p, offset.p, first_run.p, c16.p);
+        if ((rc = check("k_bs_runs"))) return rc;
         const size_t lds = sizeof(int) * 2 * (size_t)rb;
         if (rb == 8192) {
             static LdsOptIn optin;
@@ -876,7 +1025,9 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
     p.long_rows = st[1];
     p.d_c16 = c16.release();
     p.d_pvals = pvals.release();
-    p.d_dst = dst.release();
+    p.d_offset = offset.release();
+    p.d_first_run = first_run.release();
+    p.runs = nruns;
     p.d_prod = prod.release();
     p.d_r16 = acc.release();
     p.d_pbase = pbase.release();
@@ -1050,7 +1201,7 @@ static int launch_bs_sums(const spmv_csr &h, const PanelPlan &p, float *y, hipSt
 {
     const size_t lds = sizeof(float) * (size_t)(RB + kPool + kWave);
     k_bs_sums<RB><<<dim3((unsigned)p.nblocks), dim3(kWave), lds, s>>>(p.d_brow, p.d_bbase, p.d_bcnt, p.d_r16, p.d_prod, p.d_nlong, p.d_lrow, y,
-                                                                      (uint32_t)((p.bm_entries + 16) * 4), (uint32_t)((p.bm_entries + 16) * 2));
+                                                                      (uint32_t)((p.bm_entries + kBlk + 16) * 4), (uint32_t)((p.bm_entries + kBlk + 16) * 2));
     return check("k_bs_sums");
 }
 
@@ -1061,8 +1212,9 @@ int launch_binned(const spmv_csr &h, const PanelPlan &p, const float *x, float *
         const size_t lds = sizeof(float) * (size_t)kPw;
         static LdsOptIn optin;
         if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_bs_products), h.device, (int)lds)) return rc;
-        k_bs_products<<<dim3((unsigned)(p.npanels * p.splits)), dim3(kProdThreads), lds, s>>>(p.splits, h.cols, p.d_pbase, p.d_c16,
-                                                                                              p.d_pvals, p.d_dst, x, p.d_prod);
+        const unsigned grid = p.splits == 1 ? 8u * (unsigned)((p.npanels + 7) / 8) : (unsigned)(p.npanels * p.splits);
+        k_bs_products<<<dim3(grid), dim3(kProdThreads), lds, s>>>(p.splits, p.npanels, h.cols, p.d_pbase, p.d_c16,
+                                                                                              p.d_pvals, p.d_first_run, p.d_offset, x, p.d_prod);
         if (int rc = check("k_bs_products")) return rc;
         return p.bin_rows == 8192 ? launch_bs_sums<8192>(h, p, y, s) : launch_bs_sums<4096>(h, p, y, s);
     }

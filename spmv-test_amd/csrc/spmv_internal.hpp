@@ -143,10 +143,12 @@ struct PanelPlan {
     int32_t *d_lptr = nullptr;     // [nblocks + 1] first long row of every bin in d_lrow / d_lcnt
     uint32_t *d_lrow = nullptr;    // [long_rows] row in bin << 16 | first spare slot
     int32_t *d_lcnt = nullptr;     // [long_rows] spare slots of the row
-    // ... its scattered flavour: the product launch stores in bin order (d_dst), the sum launch streams d_prod + d_r16 (here:
-    // accumulator numbers) bin by bin; d_lrow = [nblocks * 2048] row << 17 | first spare accumulator << 6 | how many
+    // ... its scattered flavour: the product launch stores in bin order (d_offset, d_first_run; bit 15 of d_c16), the sum launch streams d_prod + d_r16 (here:
+    // accumulator numbers) bin by bin; d_lrow = [nblocks * 1024] row << 17 | first spare accumulator << 7 | how many
     bool scatter_mode = false;
-    int32_t *d_dst = nullptr;      // [padded] bin-major position of every panel-major entry (both interleaved in blocks of 512)
+    int32_t *d_offset = nullptr;   // [runs] bin-major minus panel-major position of a run (a nonempty tile, or a panel's pad slots)
+    int32_t *d_first_run = nullptr;   // [padded / 512] run of every 512-entry block's first entry (minus one where it starts a run)
+    int64_t runs = 0;
     int32_t *d_bbase = nullptr;    // [nblocks + 1] first entry of every bin in d_prod / d_r16 (multiples of 256)
     int32_t *d_bcnt = nullptr;     // [nblocks] entries of the bin
     int32_t *d_nlong = nullptr;    // [nblocks] rows with spare accumulators (-1: the bin adds with LDS atomics)
