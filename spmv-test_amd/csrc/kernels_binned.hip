@@ -581,8 +581,13 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                           // a step: two entries of every lane, 128 accumulators, none twice (k_bs_accs)
                 const unsigned w = c.a[u][h];
+#ifdef SPMV_BS_AB_OWNADDR      // (A/B, wrong results: loads and LDS adds, but the accumulators do not come from the loads)
+                const int a0 = live ? ((lane * 37 + u * 411 + h * 1013 + pi0 * 7) & 0xfff) : kDummy, a1 = live ? ((lane * 37 + u * 411 + h * 1013 + pi0 * 7 + 2048) & 0xfff) : kDummy + 1;
+                const float v0 = __uint_as_float(c.v[u][2 * h] ^ (w & 1u)), v1 = __uint_as_float(c.v[u][2 * h + 1] ^ (w >> 31));
+#else
                 const int a0 = live ? (int)(w & 0xffffu) : kDummy, a1 = live ? (int)(w >> 16) : kDummy + 1;
                 const float v0 = __uint_as_float(c.v[u][2 * h]), v1 = __uint_as_float(c.v[u][2 * h + 1]);
+#endif
 #ifdef SPMV_BS_AB_NOLDS        // (A/B, wrong results: the memory side alone)
                 sums[kDummy + (lane & 63)] = __uint_as_float(__float_as_uint(v0) ^ __float_as_uint(v1) ^ (unsigned)(a0 + a1));
 #else
@@ -1002,7 +1007,11 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
         k_bs_runs<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, bm, tiles.p, pm.p, pbase.p, bbase.p, run0.p, offset.p, first_run.p, c16.p);
         if ((rc = check("k_bs_runs"))) return rc;
         const size_t lds = sizeof(int) * 2 * (size_t)rb;
-        if (rb == 8192) {
+        if (rb == 16384) {
+            static LdsOptIn optin;
+            if ((rc = optin.ensure(reinterpret_cast<const void *>(&k_bs_accs<16384>), h.device, (int)lds))) return rc;
+            k_bs_accs<16384><<<dim3((unsigned)nb), dim3(kWave), lds, s>>>(brow.p, bbase.p, bcnt.p, acc.p, nlong.p, lrow.p, stats.p);
+        } else if (rb == 8192) {
             static LdsOptIn optin;
             if ((rc = optin.ensure(reinterpret_cast<const void *>(&k_bs_accs<8192>), h.device, (int)lds))) return rc;
             k_bs_accs<8192><<<dim3((unsigned)nb), dim3(kWave), lds, s>>>(brow.p, bbase.p, bcnt.p, acc.p, nlong.p, lrow.p, stats.p);
@@ -1044,11 +1053,11 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
 // scatter: the flavour whose product launch stores in bin order (thin tiles)
 int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, bool scatter, hipStream_t s)
 {
-    if (scatter && want_rows != 0 && want_rows != 4096 && want_rows != 8192) {
-        set_error("spmv_csr_plan(panel, binned, scattered products): rows per bin %d (4096 or 8192)", want_rows);
+    if (scatter && want_rows != 0 && want_rows != 4096 && want_rows != 8192 && want_rows != 16384) {
+        set_error("spmv_csr_plan(panel, binned, scattered products): rows per bin %d (4096, 8192 or 16384)", want_rows);
         return SPMV_ERR_INVALID;
     }
-    if (want_rows != 0 && want_rows != 1024 && want_rows != 2048 && want_rows != 4096 && want_rows != 8192) {
+    if (!scatter && want_rows != 0 && want_rows != 1024 && want_rows != 2048 && want_rows != 4096 && want_rows != 8192) {
         set_error("spmv_csr_plan(panel, binned): rows per bin %d (1024, 2048, 4096 or 8192)", want_rows);
         return SPMV_ERR_INVALID;
     }
@@ -1200,6 +1209,8 @@ template <int RB>
 static int launch_bs_sums(const spmv_csr &h, const PanelPlan &p, float *y, hipStream_t s)
 {
     const size_t lds = sizeof(float) * (size_t)(RB + kPool + kWave);
+    static LdsOptIn optin;
+    if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_bs_sums<RB>), h.device, (int)lds)) return rc;
     k_bs_sums<RB><<<dim3((unsigned)p.nblocks), dim3(kWave), lds, s>>>(p.d_brow, p.d_bbase, p.d_bcnt, p.d_r16, p.d_prod, p.d_nlong, p.d_lrow, y,
                                                                       (uint32_t)((p.bm_entries + kBlk + 16) * 4), (uint32_t)((p.bm_entries + kBlk + 16) * 2));
     return check("k_bs_sums");
@@ -1216,7 +1227,7 @@ int launch_binned(const spmv_csr &h, const PanelPlan &p, const float *x, float *
         k_bs_products<<<dim3(grid), dim3(kProdThreads), lds, s>>>(p.splits, p.npanels, h.cols, p.d_pbase, p.d_c16,
                                                                                               p.d_pvals, p.d_first_run, p.d_offset, x, p.d_prod);
         if (int rc = check("k_bs_products")) return rc;
-        return p.bin_rows == 8192 ? launch_bs_sums<8192>(h, p, y, s) : launch_bs_sums<4096>(h, p, y, s);
+        return p.bin_rows == 16384 ? launch_bs_sums<16384>(h, p, y, s) : p.bin_rows == 8192 ? launch_bs_sums<8192>(h, p, y, s) : launch_bs_sums<4096>(h, p, y, s);
     }
     {
         const size_t lds = sizeof(float) * (size_t)kPw;
