@@ -170,7 +170,10 @@ __global__ __launch_bounds__(kProdThreads) void k_bin_products(int splits, int64
     if (b > b0) b = b0;
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): this wave's pieces of the panel have landed
     __syncthreads();
-    for (int k = a + tid * 8; k < b; k += kProdThreads * 8) {
+    const int trips = (b - a + kProdThreads * 8 - 1) / (kProdThreads * 8);   // (counted on the scalar side, as in k_bs_products; no difference here)
+    for (int trip = 0; trip < trips; ++trip) {
+        const int k = a + trip * (kProdThreads * 8) + tid * 8;
+        if (k >= b) continue;
         const u4 c = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(c16 + k));
         const f4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(pvals + k));
         const f4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(pvals + k + 4));
@@ -502,7 +505,22 @@ __global__ __launch_bounds__(kProdThreads) void k_bs_products(int splits, int np
 #ifdef SPMV_BS_AB_NOSTORE
     float keep = 0.0f;
 #endif
-    for (int k = a + tid * 8; k < b; k += kProdThreads * 8) {       // a wavefront: one interleave block per trip
+    // The trips are counted on the scalar side (a, b and a trip are multiples of 512: a wavefront is in or out as a whole): with
+    // the lane's own k as the loop variable the compiler kept the loop under an exec mask and the product launch ran 903 us
+    // where it now runs 720 (config 5's shard).  Every workgroup walks its panel bins ascending and the workgroups of an XCD
+    // reach the same bins at about the same time -- which is what completes the shared lines in the L2: panels started at
+    // different trips of the walk (-DSPMV_BS_AB_ROT) run 923 us.  profiles/r04_scattered_products_ab_kernel_times.jsonl
+    const int trips = (b - a + kProdThreads * 8 - 1) / (kProdThreads * 8);
+#ifdef SPMV_BS_AB_ROT
+    const int rot = trips > 1 ? (int)(((unsigned)p * 2654435761u >> 8) % (unsigned)trips) : 0;
+#else
+    const int rot = 0;
+#endif
+    for (int trip = 0; trip < trips; ++trip) {                      // a wavefront: one interleave block per trip
+        int t = trip + rot;
+        t = t >= trips ? t - trips : t;
+        const int k = a + t * (kProdThreads * 8) + tid * 8;
+        if (k >= b) continue;
         const int blk = __builtin_amdgcn_readfirstlane(k >> 9);
         const int t0 = first_run[blk];
         const u4 c = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(c16 + k));
