@@ -107,11 +107,12 @@ __global__ __launch_bounds__(256) void k_bin_fill(int nb, int np, const int32_t 
                                                   const int32_t *__restrict__ pm, uint16_t *__restrict__ c16, float *__restrict__ pvals,
                                                   uint16_t *__restrict__ r16)
 {
-    extern __shared__ int cursor_all[];     // 4 x np: as many workgroups per CU as the panel count allows (a wave walks its bin alone)
+    extern __shared__ int cursor_all[];     // 4 x np: as many workgroups per CU as the panel count allows (a wave walks its bin alone); 4 x 256 tags
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + w;
     if (b >= nb) return;
     int *cursor = cursor_all + w * np;
+    volatile int *tags = cursor_all + 4 * np + w * 256;
     const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
     const int32_t *qp = pm + (int64_t)b * np;
     for (int p = lane; p < np; p += kWave) cursor[p] = tp[p];
@@ -129,7 +130,12 @@ __global__ __launch_bounds__(256) void k_bin_fill(int nb, int np, const int32_t 
         }
         const int p = col >> kPwBits;
         int dest = 0;
-        unsigned long long todo = __ballot(valid);
+        const bool lone = lone_in_step(tags, valid, p, lane);       // the only nonzero of its panel in this step
+        if (lone) {
+            dest = cursor[p];
+            cursor[p] = dest + 1;
+        }
+        unsigned long long todo = __ballot(valid && !lone);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int pl = __shfl(p, leader);
@@ -304,11 +310,12 @@ __global__ __launch_bounds__(256) void k_bs_fill(int nb, int np, const int32_t *
                                                  const int32_t *__restrict__ pm, const int32_t *__restrict__ bbase,
                                                  uint16_t *__restrict__ c16, float *__restrict__ pvals, uint16_t *__restrict__ acc)
 {
-    extern __shared__ int cursor_all[];     // 4 x np
+    extern __shared__ int cursor_all[];     // 4 x np cursors, 4 x 256 tags
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + w;
     if (b >= nb) return;
     int *cursor = cursor_all + w * np;
+    volatile int *tags = cursor_all + 4 * np + w * 256;
     const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
     const int32_t *qp = pm + (int64_t)b * np;
     for (int p = lane; p < np; p += kWave) cursor[p] = tp[p];
@@ -327,7 +334,12 @@ __global__ __launch_bounds__(256) void k_bs_fill(int nb, int np, const int32_t *
         }
         const int p = col >> kPwBits;
         int dest = 0;
-        unsigned long long todo = __ballot(valid);
+        const bool lone = lone_in_step(tags, valid, p, lane);       // the only nonzero of its panel in this step
+        if (lone) {
+            dest = cursor[p];
+            cursor[p] = dest + 1;
+        }
+        unsigned long long todo = __ballot(valid && !lone);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int pl = __shfl(p, leader);
@@ -1019,7 +1031,7 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
     int32_t st[2] = {0, 0};
     if (h.nnz > 0) {
         if ((rc = panel_rowloc(h, brow.p, nb, rowloc.p, s))) return rc;
-        k_bs_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), sizeof(int) * 4 * (size_t)np, s>>>(
+        k_bs_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), sizeof(int) * 4 * ((size_t)np + 256), s>>>(
             nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, tiles.p, pm.p, bbase.p, c16.p, pvals.p, acc.p);
         if ((rc = check("k_bs_fill"))) return rc;
         k_bs_runs<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, bm, tiles.p, pm.p, pbase.p, bbase.p, run0.p, offset.p, first_run.p, c16.p);
@@ -1147,7 +1159,7 @@ int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, bool scatter, hipStrea
     SPMV_HIP_TRY(hipMemsetAsync(pvals.p, 0, sizeof(float) * nslot, s));
     if (h.nnz > 0) {
         if ((rc = panel_rowloc(h, brow.p, nb, rowloc.p, s))) return rc;
-        k_bin_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), sizeof(int) * 4 * (size_t)np, s>>>(
+        k_bin_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), sizeof(int) * 4 * ((size_t)np + 256), s>>>(
             nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, tiles.p, pm.p, c16.p, pvals.p, r16.p);
         if ((rc = check("k_bin_fill"))) return rc;
     }

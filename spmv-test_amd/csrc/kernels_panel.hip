@@ -184,10 +184,12 @@ __global__ __launch_bounds__(256) void k_panel_fill(int nblocks, const int32_t *
                                                     uint32_t *__restrict__ packed, float *__restrict__ pvals)
 {
     __shared__ int cursor_all[4][kMaxPanels];
+    __shared__ int tags_all[4][256];
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
     const int wb = blockIdx.x * 4 + w;
     if (wb >= nblocks) return;
     int *cursor = cursor_all[w];
+    volatile int *tags = tags_all[w];
     const int32_t *tp = tile_ptr + (int64_t)wb * (np + 1);
     for (int p = lane; p < np; p += kWave) cursor[p] = tp[p];
     const int s = row_ptr[brow[wb]], e = row_ptr[brow[wb + 1]];
@@ -205,7 +207,12 @@ __global__ __launch_bounds__(256) void k_panel_fill(int nblocks, const int32_t *
         }
         const int p = col >> pw_bits;
         int dest = 0;
-        unsigned long long todo = __ballot(valid);
+        const bool lone = lone_in_step(tags, valid, p, lane);       // the only nonzero of its panel in this step
+        if (lone) {
+            dest = cursor[p];
+            cursor[p] = dest + 1;
+        }
+        unsigned long long todo = __ballot(valid && !lone);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int pl = __shfl(p, leader);

@@ -299,4 +299,25 @@ int synth_fill(uint64_t seed, int64_t row0, int64_t n_local, int64_t rows, int64
                const int32_t *d_row_ptr, int32_t *d_col_idx, float *d_vals, hipStream_t s);
 int synth_x(uint64_t seed, int64_t j0, int64_t n, float *d_x, hipStream_t s);
 
+
+#if defined(__HIPCC__)
+// Stable scatter by key, 64 entries per step (k_panel_fill, k_bin_fill, k_bs_fill): which lanes hold a key that NO other lane of
+// the step holds?  They take their cursor and bump it themselves; only the keys held twice go through the ballot loop -- on
+// uniform columns over thousands of panels that is one or two trips instead of 64.  `tags` = 256 words of the wavefront's
+// own LDS, hashed by the key's low bits: two keys in one slot both go to the loop (conservative, never wrong).
+__device__ __forceinline__ bool lone_in_step(volatile int *tags, bool valid, int key, int lane)
+{
+    const int slot = key & 255;
+    if (valid) tags[slot] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const int first = valid ? tags[slot] : lane;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && first != lane) tags[slot] = kWave;                 // somebody else's slot too: nobody in it is alone
+    __builtin_amdgcn_wave_barrier();
+    const int second = valid ? tags[slot] : kWave;
+    __builtin_amdgcn_wave_barrier();
+    return valid && second == lane;
+}
+#endif
+
 }  // namespace spmv
