@@ -635,6 +635,27 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
     };
     // two register sets, both in flight at the top of the loop (as in k_bin_sums)
     auto stream = [&](auto flagged) {
+#ifdef SPMV_BS_AB_SETS3        // (A/B: three register sets in flight instead of two)
+        Set sa, sb, sc;
+        __builtin_amdgcn_sched_barrier(0);
+        issue(0, sa);
+        issue(kD, sb);
+        issue(2 * kD, sc);
+        for (int pi0 = 0; pi0 < pieces; pi0 += 3 * kD) {
+            __builtin_amdgcn_sched_barrier(0);
+            consume(pi0, sa, flagged);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(pi0 + 3 * kD, sa);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(pi0 + kD, sb, flagged);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(pi0 + 4 * kD, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(pi0 + 2 * kD, sc, flagged);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(pi0 + 5 * kD, sc);
+        }
+#else
         Set sa, sb;
         __builtin_amdgcn_sched_barrier(0);
         issue(0, sa);
@@ -650,6 +671,7 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
             __builtin_amdgcn_sched_barrier(0);
             issue(pi0 + 3 * kD, sb);
         }
+#endif
     };
 #ifdef SPMV_BS_AB_ATOMIC       // (A/B: every bin through the LDS atomics; right results where no spare accumulators are in use)
     stream(std::true_type());

@@ -38,7 +38,8 @@ def test_run_is_graph_capturable(pkg, oracle, gpu):
     # the panel family too: the sweep, the sorted blocks and the binned layout (two launches + the scratch products) through
     # spmv_csr_plan_set, and SPMV_WAVE on short rows (the bundles and the long rows' pieces: three launches)
     for name, params in (("panel sweep", [pkg.capi.PANEL, 0, 0, 0, 0, 0, 1, 0]), ("sorted blocks", [pkg.capi.PANEL, 0, 0, 0, 0, 0, 3, 0]),
-                         ("binned", [pkg.capi.PANEL, 0, 0, 0, 0, 0, 4, 0]), ("wave", None)):
+                         ("binned", [pkg.capi.PANEL, 0, 0, 0, 0, 0, 4, 0]), ("binned, scattered products", [pkg.capi.PANEL, 0, 0, 0, 0, 0, 5, 0]),
+                         ("wave", None)):
         v = pkg.capi.PANEL if params else pkg.capi.WAVE
         if params:
             prob.A.plan_set(v, params)
