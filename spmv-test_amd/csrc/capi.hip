@@ -360,13 +360,16 @@ static int plan_auto(spmv_csr &h, hipStream_t s)
         // x beyond every L2 (each gather would be a 128-byte line from the fabric) and tiles that still hold a line or
         // two of products: the binned layout -- two streaming launches, nothing gathered from memory
         // (measured, profiles/r04_binned_*.jsonl: config 4 uniform 1.33 -> 1.06 ms at 83 nonzeros per tile, config 3 uniform
-        // 0.86 -> 0.52 ms at 663; config 5's shard 3.0 -> 4.1 ms at 10: below ~48 the sum launch works on quarter-empty pieces)
+        // 0.86 -> 0.52 ms at 663; config 5's shard 3.0 -> 4.1 ms at 10: the sum launch works on nearly empty pieces)
         // Thinner tiles (config 5's shard: 14 at 4096 rows per bin, 28 at 8192): the flavour whose product launch stores in bin
-        // order -- the sum launch then streams whatever the tiles hold (3.0 -> 1.55 ms there, the sweep with its shorter step 2.4;
-        // at config 4 it reads 1.24 ms against 1.04: the destinations are 4 more bytes per nonzero and the stores come in runs)
+        // order -- the sum launch then streams whatever the tiles hold (3.0 -> 1.12 ms there, the sweep with its shorter step 2.4).
+        // Constant rows of 8 / 10 / 12 / 16 / 24 on 16Mi x 16Mi (64 ... 192 nonzeros per 4096 rows x 32768 columns): 0.55 / 0.67 /
+        // 0.78 / 1.01 / 1.50 ms against the fetching flavour's 0.69 / 0.78 / 0.87 / 1.06 / 1.53 (profiles/
+        // r04_binned_flavours_by_tile.jsonl), config 4 itself (128) 0.99 against 1.01; config 3 (1024, a third of the nonzeros in
+        // long rows) 0.81 against 0.54: from 256 up the fetching flavour
         const bool big_x = h.cols * (int64_t)sizeof(float) >= (8ll << 20);
         const double tile = binned_tile_nonzeros(h, 4096);
-        int try_binned = big_x && tile >= 48.0 ? 4 : big_x && 2.0 * tile >= 8.0 ? 5 : 0;
+        int try_binned = big_x && tile >= 256.0 ? 4 : big_x && tile >= 4.0 ? 5 : 0;
         if (const char *e = getenv("SPMV_AUTO_BINNED")) try_binned = atoi(e) != 0 ? try_binned : 0;   // 0: never (A/B runs)
         if (try_binned) {
             rc = build_panel(h, h.plan_auto_panel, 0, 0, try_binned, s);

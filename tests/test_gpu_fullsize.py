@@ -157,14 +157,13 @@ def test_binned_layout_forced_at_full_size(c4, pkg, mode):
 
 def test_auto_choice_at_full_size(c4, pkg):
     """SPMV_AUTO at the BASELINE sizes: the LDS-tiled kernel on a band of 8192 columns; on uniform columns the binned layout
-    of the panel family (round 4: two streaming launches) -- the sum launch fetching the tiles where a (bin, panel) tile
-    holds dozens of nonzeros, config 4; the product launch storing in bin order where it holds 14-28, config 5's shard,
-    128Mi columns; the sorted blocks of the panel family on a band of 1M columns (65 536: whichever the models price lower)."""
+    of the panel family (round 4: two streaming launches), the flavour whose product launch stores in bin order -- config 4
+    (128 nonzeros per 4096 rows x 32768 columns) and config 5's shard (16; 128Mi columns); the fetching flavour takes over
+    from 256 (config 3, 1024: tests/test_gpu_binned.py); the sorted blocks of the panel family on a band of 1M columns (65 536: whichever
+    the models price lower)."""
     d = c4["A"].plan_describe(pkg.capi.AUTO)
     band = c4["w"].band
-    if band == 0 and c4["w"].cols == c4["w"].rows and c4["A"].rows == c4["w"].rows:
-        assert d.startswith("auto -> panel: binned bins="), d
-    elif band == 0:
+    if band == 0:       # config 4: 128 nonzeros per 4096 rows x 32768 columns; config 5's shard: 16 -- both below the 256 from which the fetching flavour takes over
         assert d.startswith("auto -> panel: binned scattered_products bins="), d
     elif band <= 8192:
         assert d.startswith("auto -> tiled"), d
