@@ -365,11 +365,12 @@ static int plan_auto(spmv_csr &h, hipStream_t s)
         // order -- the sum launch then streams whatever the tiles hold (3.0 -> 1.12 ms there, the sweep with its shorter step 2.4).
         // Constant rows of 8 / 10 / 12 / 16 / 24 on 16Mi x 16Mi (64 ... 192 nonzeros per 4096 rows x 32768 columns): 0.55 / 0.67 /
         // 0.78 / 1.01 / 1.50 ms against the fetching flavour's 0.69 / 0.78 / 0.87 / 1.06 / 1.53 (profiles/
-        // r04_binned_flavours_by_tile.jsonl), config 4 itself (128) 0.99 against 1.01; config 3 (1024, a third of the nonzeros in
-        // long rows) 0.81 against 0.54: from 256 up the fetching flavour
+        // r04_binned_flavours_by_tile.jsonl), config 4 itself (128) 0.97 against 1.01, config 3 (1024, a third of the nonzeros in
+        // long rows) 0.52 against 0.54 once it has a bin per resident wavefront: the fetching flavour (mode 4) is never the
+        // rule's answer any more; it stays selectable
         const bool big_x = h.cols * (int64_t)sizeof(float) >= (8ll << 20);
         const double tile = binned_tile_nonzeros(h, 4096);
-        int try_binned = big_x && tile >= 256.0 ? 4 : big_x && tile >= 4.0 ? 5 : 0;
+        int try_binned = big_x && tile >= 4.0 ? 5 : 0;
         if (const char *e = getenv("SPMV_AUTO_BINNED")) try_binned = atoi(e) != 0 ? try_binned : 0;   // 0: never (A/B runs)
         if (try_binned) {
             rc = build_panel(h, h.plan_auto_panel, 0, 0, try_binned, s);

@@ -1142,7 +1142,15 @@ int plan_binned(spmv_csr &h, PanelPlan &p, int want_rows, bool scatter, hipStrea
     // (wavefronts that carry equal loads finish together; the cuts aim at 0.8 rb rows so that hardly any needs splitting)
     const int64_t slots = (int64_t)cus * ((rb + kSpare + kWave) * 4 * kSumWaves <= 80 * 1024 ? 2 : 1) * kSumWaves;
     int64_t nb0 = slots * ((h.rows * 5 / 4 + (int64_t)rb * slots - 1) / ((int64_t)rb * slots));
-    if (scatter) nb0 = (h.rows * 9 / 8 + rb - 1) / rb;        // (thin tiles: as many rows per bin as the cuts allow)
+    if (scatter) {
+        // as many rows per bin as the cuts allow (fat runs for the product launch) -- but a bin per wavefront the sum launch
+        // keeps resident at least: config 3 (4Mi rows) 576 bins of 8192 rows ran 0.81 ms, 1024 bins of 4096 0.52
+        // (profiles/r04_scattered_bins.jsonl; more bins than that change little: the launch is not bound by its rounds)
+        nb0 = (h.rows * 9 / 8 + rb - 1) / rb;
+        const int64_t resident = (int64_t)cus * (rb == 4096 ? 7 : rb == 8192 ? 4 : 2);
+        if (nb0 < resident) nb0 = resident;
+        if (const char *e = getenv("SPMV_BS_BINS")) { const long long v = atoll(e); if (v > 0) nb0 = v; }   // (A/B runs)
+    }
     if (nb0 > h.rows) nb0 = h.rows;
     DevPtr<int32_t> brow;
     int rc = panel_row_blocks(h, nb0, rb, s, brow, &p.nblocks);

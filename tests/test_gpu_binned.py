@@ -211,7 +211,8 @@ def test_binned_edge_shapes_and_stale_values(pkg, oracle, gpu):
 
 
 def test_auto_resolves_to_binned_where_x_is_beyond_the_caches(pkg, oracle, gpu):
-    """Uniform columns over 16 MiB of x (config 3's size): SPMV_AUTO takes the binned layout and its y passes the oracle."""
+    """Uniform columns over 16 MiB of x (config 3's size): SPMV_AUTO takes the binned layout (its scattered flavour, a bin per
+    resident wavefront) and its y passes the oracle."""
     import torch
     capi = pkg.capi
     w = pkg.workloads.config("c3", band=0)
@@ -226,7 +227,7 @@ def test_auto_resolves_to_binned_where_x_is_beyond_the_caches(pkg, oracle, gpu):
     A = capi.CsrMatrix.from_device(w.rows, w.cols, d_rp, d_ci, d_va)
     A.plan(capi.AUTO)
     d = A.plan_describe(capi.AUTO)
-    assert d.startswith("auto -> panel: binned bins="), d
+    assert d.startswith("auto -> panel: binned scattered_products bins=1024 "), d
     A.run(capi.AUTO, d_x, d_y)
     torch.cuda.synchronize()
     # a window of rows regenerated on the host

@@ -158,12 +158,12 @@ def test_binned_layout_forced_at_full_size(c4, pkg, mode):
 def test_auto_choice_at_full_size(c4, pkg):
     """SPMV_AUTO at the BASELINE sizes: the LDS-tiled kernel on a band of 8192 columns; on uniform columns the binned layout
     of the panel family (round 4: two streaming launches), the flavour whose product launch stores in bin order -- config 4
-    (128 nonzeros per 4096 rows x 32768 columns) and config 5's shard (16; 128Mi columns); the fetching flavour takes over
-    from 256 (config 3, 1024: tests/test_gpu_binned.py); the sorted blocks of the panel family on a band of 1M columns (65 536: whichever
+    (128 nonzeros per 4096 rows x 32768 columns) and config 5's shard (16; 128Mi columns); config 3 too
+    (tests/test_gpu_binned.py); the sorted blocks of the panel family on a band of 1M columns (65 536: whichever
     the models price lower)."""
     d = c4["A"].plan_describe(pkg.capi.AUTO)
     band = c4["w"].band
-    if band == 0:       # config 4: 128 nonzeros per 4096 rows x 32768 columns; config 5's shard: 16 -- both below the 256 from which the fetching flavour takes over
+    if band == 0:       # config 4: 128 nonzeros per 4096 rows x 32768 columns; config 5's shard: 16
         assert d.startswith("auto -> panel: binned scattered_products bins="), d
     elif band <= 8192:
         assert d.startswith("auto -> tiled"), d
