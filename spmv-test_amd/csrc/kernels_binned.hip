@@ -514,24 +514,15 @@ __global__ __launch_bounds__(kProdThreads) void k_bs_products(int splits, int np
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): this wave's pieces of the panel have landed
     __syncthreads();
     const unsigned long long le = (2ull << lane) - 1ull;            // this lane and the ones below
-#ifdef SPMV_BS_AB_NOSTORE
-    float keep = 0.0f;
-#endif
     // The trips are counted on the scalar side (a, b and a trip are multiples of 512: a wavefront is in or out as a whole): with
     // the lane's own k as the loop variable the compiler kept the loop under an exec mask and the product launch ran 903 us
     // where it now runs 720 (config 5's shard).  Every workgroup walks its panel bins ascending and the workgroups of an XCD
-    // reach the same bins at about the same time -- which is what completes the shared lines in the L2: panels started at
-    // different trips of the walk (-DSPMV_BS_AB_ROT) run 923 us.  profiles/r04_scattered_products_ab_kernel_times.jsonl
+    // reach the same bins at about the same time -- which is what completes the shared lines in the L2: with the panels
+    // started at different trips of the walk (tried against a suspected channel hot spot) the launch ran 923 us.
+    // profiles/r04_scattered_products_ab_kernel_times.jsonl (the A/B builds behind it: the tree of commit 46593cb)
     const int trips = (b - a + kProdThreads * 8 - 1) / (kProdThreads * 8);
-#ifdef SPMV_BS_AB_ROT
-    const int rot = trips > 1 ? (int)(((unsigned)p * 2654435761u >> 8) % (unsigned)trips) : 0;
-#else
-    const int rot = 0;
-#endif
     for (int trip = 0; trip < trips; ++trip) {                      // a wavefront: one interleave block per trip
-        int t = trip + rot;
-        t = t >= trips ? t - trips : t;
-        const int k = a + t * (kProdThreads * 8) + tid * 8;
+        const int k = a + trip * (kProdThreads * 8) + tid * 8;
         if (k >= b) continue;
         const int blk = __builtin_amdgcn_readfirstlane(k >> 9);
         const int t0 = first_run[blk];
@@ -548,16 +539,9 @@ __global__ __launch_bounds__(kProdThreads) void k_bs_products(int splits, int np
             const int d = offset[run + __popcll(starts & le)];
             run += __popcll(starts);
             const float o = xp[cw[j] & (unsigned)(kPw - 1)] * vw[j];
-#ifdef SPMV_BS_AB_NOSTORE      // (A/B, wrong results: everything but the stores)
-            keep += o + (float)d;
-#else
             prod[q + 64 * j + d] = o;
-#endif
         }
     }
-#ifdef SPMV_BS_AB_NOSTORE
-    prod[tid & 15] = keep;
-#endif
 }
 
 // launch 2 of this flavour: a wavefront per bin, its products and accumulator numbers one contiguous stream
@@ -587,18 +571,8 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
 #pragma unroll
         for (int u = 0; u < kD; ++u) {
             const unsigned at = (unsigned)base + (unsigned)(pi0 + u) * kBmPiece;
-#ifdef SPMV_BS_AB_NOLOAD       // (A/B, wrong results: the LDS side alone; 1 = random accumulators, 2 = one bank per lane)
-            c.v[u] = u4v{at, at, at, at};
-            {
-                unsigned h0 = (at + (unsigned)lane * 0x9E3779B1u) * 0x85EBCA6Bu, h1 = (h0 ^ (h0 >> 13)) * 0xC2B2AE35u;
-                h0 ^= h0 >> 16; h1 ^= h1 >> 15;
-                if (SPMV_BS_AB_NOLOAD == 2) { h0 = (h0 & 0x0fc00fc0u) | (unsigned)lane | ((unsigned)lane << 16) ^ 0x00200000u; h1 = (h1 & 0x0fc00fc0u) | (unsigned)lane | ((unsigned)lane << 16) ^ 0x00200000u; }
-                c.a[u] = u2v{h0 & 0x0fff0fffu, h1 & 0x0fff0fffu};
-            }
-#else
             c.v[u] = __builtin_amdgcn_raw_buffer_load_b128(pr, lane * 16, (int)(at * 4u), 0);
             c.a[u] = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, (int)(at * 2u), 0);
-#endif
             // the SAME order of loads before the loop and inside it: the wait counts are static, and a first trip that needs
             // "everything" (the scheduler had turned the sets round) makes every trip wait for everything
             __builtin_amdgcn_sched_barrier(0);
@@ -611,16 +585,8 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                           // a step: two entries of every lane, 128 accumulators, none twice (k_bs_accs)
                 const unsigned w = c.a[u][h];
-#ifdef SPMV_BS_AB_OWNADDR      // (A/B, wrong results: loads and LDS adds, but the accumulators do not come from the loads)
-                const int a0 = live ? ((lane * 37 + u * 411 + h * 1013 + pi0 * 7) & 0xfff) : kDummy, a1 = live ? ((lane * 37 + u * 411 + h * 1013 + pi0 * 7 + 2048) & 0xfff) : kDummy + 1;
-                const float v0 = __uint_as_float(c.v[u][2 * h] ^ (w & 1u)), v1 = __uint_as_float(c.v[u][2 * h + 1] ^ (w >> 31));
-#else
                 const int a0 = live ? (int)(w & 0xffffu) : kDummy, a1 = live ? (int)(w >> 16) : kDummy + 1;
                 const float v0 = __uint_as_float(c.v[u][2 * h]), v1 = __uint_as_float(c.v[u][2 * h + 1]);
-#endif
-#ifdef SPMV_BS_AB_NOLDS        // (A/B, wrong results: the memory side alone)
-                sums[kDummy + (lane & 63)] = __uint_as_float(__float_as_uint(v0) ^ __float_as_uint(v1) ^ (unsigned)(a0 + a1));
-#else
                 if (decltype(flagged)::value) {
                     atomicAdd(&sums[a0], v0);
                     atomicAdd(&sums[a1], v1);
@@ -629,33 +595,11 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
                     sums[a0] = s0 + v0;
                     sums[a1] = s1 + v1;
                 }
-#endif
             }
         }
     };
     // two register sets, both in flight at the top of the loop (as in k_bin_sums)
     auto stream = [&](auto flagged) {
-#ifdef SPMV_BS_AB_SETS3        // (A/B: three register sets in flight instead of two)
-        Set sa, sb, sc;
-        __builtin_amdgcn_sched_barrier(0);
-        issue(0, sa);
-        issue(kD, sb);
-        issue(2 * kD, sc);
-        for (int pi0 = 0; pi0 < pieces; pi0 += 3 * kD) {
-            __builtin_amdgcn_sched_barrier(0);
-            consume(pi0, sa, flagged);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(pi0 + 3 * kD, sa);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(pi0 + kD, sb, flagged);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(pi0 + 4 * kD, sb);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(pi0 + 2 * kD, sc, flagged);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(pi0 + 5 * kD, sc);
-        }
-#else
         Set sa, sb;
         __builtin_amdgcn_sched_barrier(0);
         issue(0, sa);
@@ -671,14 +615,9 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
             __builtin_amdgcn_sched_barrier(0);
             issue(pi0 + 3 * kD, sb);
         }
-#endif
     };
-#ifdef SPMV_BS_AB_ATOMIC       // (A/B: every bin through the LDS atomics; right results where no spare accumulators are in use)
-    stream(std::true_type());
-#else
     if (nl >= 0) stream(std::false_type());
     else stream(std::true_type());                                  // flagged bin (wave-uniform): LDS atomics
-#endif
     for (int i = lane; i < nl; i += kWave) {                        // the spare accumulators join their rows, in order
         const uint32_t w = lrow[(int64_t)b * kPool + i];
         const int row = (int)(w >> 17), first = RB + (int)((w >> 7) & 0x3ffu), cnt = (int)(w & 127u);
