@@ -1,4 +1,7 @@
-// kernels_binned.hip -- SPMV_PANEL mode 4, "binned": y = A x for columns WITHOUT locality as two pure streams.
+// kernels_binned.hip -- SPMV_PANEL modes 4 and 5, "binned": y = A x for columns WITHOUT locality as two pure streams.
+// Two flavours: mode 4 (the first: the SUM launch fetches the tiles from panel-major products; described right here) and
+// mode 5 (the PRODUCT launch stores every product where the sum launch streams it; "the SCATTERED flavour" further down --
+// what SPMV_AUTO takes since it turned out at least as fast everywhere the two were put side by side).
 //
 // Why.  The reference's only structure law is i.i.d. uniform positions
 // (/root/reference/src/tester.cpp:103-121).  On such a matrix every gather design of this library pays one L2 line
