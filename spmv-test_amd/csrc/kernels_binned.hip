@@ -542,7 +542,11 @@ __global__ __launch_bounds__(kProdThreads) void k_bs_products(int splits, int np
             const int d = offset[run + __popcll(starts & le)];
             run += __popcll(starts);
             const float o = xp[cw[j] & (unsigned)(kPw - 1)] * vw[j];
+#ifdef SPMV_BS_NT_STORE
+            __builtin_nontemporal_store(o, prod + (q + 64 * j + d));
+#else
             prod[q + 64 * j + d] = o;
+#endif
         }
     }
 }
@@ -557,6 +561,9 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
 {
 #ifndef SPMV_BS_DEPTH
 #define SPMV_BS_DEPTH 4
+#endif
+#ifndef SPMV_BS_LOAD_AUX
+#define SPMV_BS_LOAD_AUX 2      // cache-policy bits of the sum launch's loads: non-temporal (0: 398 -> 360 us at config 5's shard; the products are read once)
 #endif
     constexpr int kDummy = RB + kPool, kD = SPMV_BS_DEPTH;           // pieces per register set (two sets in flight)
     extern __shared__ float sums[];                                 // RB + kPool + kWave
@@ -574,8 +581,8 @@ __global__ __launch_bounds__(kWave) void k_bs_sums(const int32_t *__restrict__ b
 #pragma unroll
         for (int u = 0; u < kD; ++u) {
             const unsigned at = (unsigned)base + (unsigned)(pi0 + u) * kBmPiece;
-            c.v[u] = __builtin_amdgcn_raw_buffer_load_b128(pr, lane * 16, (int)(at * 4u), 0);
-            c.a[u] = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, (int)(at * 2u), 0);
+            c.v[u] = __builtin_amdgcn_raw_buffer_load_b128(pr, lane * 16, (int)(at * 4u), SPMV_BS_LOAD_AUX);
+            c.a[u] = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, (int)(at * 2u), SPMV_BS_LOAD_AUX);
             // the SAME order of loads before the loop and inside it: the wait counts are static, and a first trip that needs
             // "everything" (the scheduler had turned the sets round) makes every trip wait for everything
             __builtin_amdgcn_sched_barrier(0);
@@ -674,6 +681,9 @@ __device__ __forceinline__ void fold_piece(int lane, int cnt, int &row, float &v
 // of the tile, no step ever holds a row twice, and the add is a plain LDS read-add-write with NO fold logic at all.  The
 // plan flags the few tiles where a row does hold more (bit 31 of their pm entry): those go, 64 products at a time, one per
 // lane, through the segmented scan above.  Dead entries (past the tile's end) add into a dummy word behind the sums.
+#ifndef SPMV_BIN_LOAD_AUX
+#define SPMV_BIN_LOAD_AUX 0     // cache-policy bits of the piece loads (A/B builds: 2 = non-temporal)
+#endif
 template <int RB, int E>
 __global__ __launch_bounds__(kSumWaves *kWave) void k_bin_sums(int nb, int np, const int32_t *__restrict__ brow,
                                                                const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ pm,
@@ -734,21 +744,21 @@ __global__ __launch_bounds__(kSumWaves *kWave) void k_bin_sums(int nb, int np, c
                 // address arithmetic per piece on the vector side (reads past the arrays' ends return 0)
                 const unsigned qb = (unsigned)((q & 0x7fffffff) + off) * 4u, sb = (unsigned)(s + off) * 2u;
                 if (E == 4) {
-                    const auto pv = __builtin_amdgcn_raw_buffer_load_b128(pr, lane * 16, (int)qb, 0);
+                    const auto pv = __builtin_amdgcn_raw_buffer_load_b128(pr, lane * 16, (int)qb, SPMV_BIN_LOAD_AUX);
                     c.v[u][0] = __uint_as_float(pv[0]); c.v[u][1] = __uint_as_float(pv[1]);
                     c.v[u][2] = __uint_as_float(pv[2]); c.v[u][3] = __uint_as_float(pv[3]);
                 } else {
-                    const auto pv = __builtin_amdgcn_raw_buffer_load_b64(pr, lane * 8, (int)qb, 0);
+                    const auto pv = __builtin_amdgcn_raw_buffer_load_b64(pr, lane * 8, (int)qb, SPMV_BIN_LOAD_AUX);
                     c.v[u][0] = __uint_as_float(pv[0]); c.v[u][1] = __uint_as_float(pv[1]);
                 }
                 // (the rows of a lane: one load; a tile starts at any entry, so the address is 2-byte aligned only -- the
                 // memory pipeline takes that, as it does for the global loads the compiler makes of a uint16_t pointer)
                 if (E == 4) {
-                    const auto rv = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, (int)sb, 0);
+                    const auto rv = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, (int)sb, SPMV_BIN_LOAD_AUX);
                     c.r[u][0] = (int)(rv[0] & 0xffffu); c.r[u][1] = (int)(rv[0] >> 16);
                     c.r[u][2] = (int)(rv[1] & 0xffffu); c.r[u][3] = (int)(rv[1] >> 16);
                 } else {
-                    const unsigned rv = __builtin_amdgcn_raw_buffer_load_b32(rr, lane * 4, (int)sb, 0);
+                    const unsigned rv = __builtin_amdgcn_raw_buffer_load_b32(rr, lane * 4, (int)sb, SPMV_BIN_LOAD_AUX);
                     c.r[u][0] = (int)(rv & 0xffffu); c.r[u][1] = (int)(rv >> 16);
                 }
             }
