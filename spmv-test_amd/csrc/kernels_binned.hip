@@ -972,7 +972,7 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
     SPMV_HIP_TRY(hipMemcpyAsync(&bm, total.p, sizeof bm, hipMemcpyDeviceToHost, s));
     SPMV_HIP_TRY(hipMemcpyAsync(bbase.p + nb, total.p, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     SPMV_HIP_TRY(hipStreamSynchronize(s));
-    if (bm < 0 || (int64_t)bm > (1ll << 30) - 64) {   // (h.nnz + 256 per bin: the check of plan_binned leaves this much)
+    if (bm < 0 || (int64_t)bm > (1ll << 30) - 1024) {   // ((bm + 528) * 4 bytes must fit the buffer descriptors' 32 bits)
         set_error("spmv_csr_plan(panel, binned, scattered products): %d bins pad nnz %lld beyond 2^30 entries", nb, (long long)h.nnz);
         return SPMV_ERR_INVALID;
     }
