@@ -361,6 +361,95 @@ __global__ __launch_bounds__(256) void k_bs_fill(int nb, int np, const int32_t *
     }
 }
 
+
+// The fill in two passes (what plan_scatter runs; k_bs_fill above is the one-pass form, SPMV_BS_FILL=1).  One pass stores
+// every nonzero of a bin at its tile -- 4096 tiles per bin at config 5's shard, 28 nonzeros each, filled over the whole
+// life of the bin's wavefront: a 2-byte and a 4-byte store all over the panel-major arrays and a 2-byte store over the
+// bin's region per nonzero, every line written a few bytes at a time (44 ms).  Two passes keep the writes of a tile close
+// in time: (1) k_bs_group -- a wavefront per bin, the nonzeros into GROUPS of 64 panels inside the bin's own bin-major
+// range (64 cursors: the lines being filled stay in the L2); (2) k_bs_place -- a wavefront per (group, bin), 64 tiles, a
+// few hundred nonzeros: every tile is written within microseconds, by the XCD that also writes its neighbours in the panel.
+// Inside a tile the nonzeros come in the order the LDS atomics of the two passes hand out places -- the same on every run,
+// not the one-pass fill's ascending rows: this flavour needs no order inside a tile (k_bs_accs ranks what is there).
+constexpr int kGroupBits = 6;              // panels per group: 64 (a lane's worth of cursors)
+__global__ __launch_bounds__(256) void k_bs_group(int nb, int np, const int32_t *__restrict__ brow, const int32_t *__restrict__ row_ptr,
+                                                  const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
+                                                  const uint16_t *__restrict__ rowloc, const int32_t *__restrict__ tile_ptr,
+                                                  int32_t *__restrict__ tcol, float *__restrict__ tval, uint16_t *__restrict__ trow)
+{
+    __shared__ int cursor_all[4][64];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= nb) return;
+    int *cursor = cursor_all[w];
+    const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+    const int ng = (np + 63) >> kGroupBits;                         // <= 64
+    if (lane < ng) cursor[lane] = tp[lane << kGroupBits];
+    const int s = row_ptr[brow[b]], e = row_ptr[brow[b + 1]];
+    for (int base = s; base < e; base += kWave) {
+        const int k = base + lane;
+        const bool valid = k < e;
+        int col = 0, rl = 0;
+        float v = 0.0f;
+        if (valid) {
+            col = col_idx[k];
+            rl = rowloc[k];
+            v = vals[k];
+        }
+        const int g = col >> (kPwBits + kGroupBits);
+        // (64 keys on 64 lanes: every key is held several times over and the ballot loop of the one-pass fill would take
+        // ~40 trips per step -- an LDS atomic with return hands out the places; the order inside a group is then the order
+        // the LDS serves the lanes in, the same on every run, and nothing downstream needs the rows of a tile ascending)
+        const int dest = valid ? atomicAdd(&cursor[g], 1) : 0;
+        if (valid) {
+            tcol[dest] = col;
+            tval[dest] = v;
+            trow[dest] = (uint16_t)rl;
+        }
+    }
+}
+// pass 2: item (group g, bin b), b fastest, the items dealt to the XCDs in contiguous ranges.  src_*: the grouped copies of
+// pass 1, or -- one group only -- the CSR arrays themselves (a bin's bin-major range IS its CSR range)
+__global__ __launch_bounds__(256) void k_bs_place(int nb, int np, int nitems, const int32_t *__restrict__ src_col, const float *__restrict__ src_val,
+                                                  const uint16_t *__restrict__ src_row, const int32_t *__restrict__ tile_ptr,
+                                                  const int32_t *__restrict__ pm, const int32_t *__restrict__ bbase,
+                                                  uint16_t *__restrict__ c16, float *__restrict__ pvals, uint16_t *__restrict__ acc)
+{
+    __shared__ int cursor_all[4][64];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int nwg = (int)gridDim.x, per8 = (nwg + 7) >> 3;
+    const int wg = (int)(blockIdx.x & 7u) * per8 + (int)(blockIdx.x >> 3);   // (the grid is 8 per8 workgroups)
+    const int item = wg * 4 + w;
+    if (wg >= (nitems + 3) / 4 || item >= nitems) return;
+    const int g = item / nb, b = item - g * nb;
+    int *cursor = cursor_all[w];
+    const int32_t *tp = tile_ptr + (int64_t)b * (np + 1);
+    const int32_t *qp = pm + (int64_t)b * np;
+    const int p0 = g << kGroupBits, p1 = p0 + 64 < np ? p0 + 64 : np;
+    if (p0 + lane < p1) cursor[lane] = tp[p0 + lane];
+    const int s = tp[p0], e = tp[p1];
+    const int shift = bbase[b] - tp[0];
+    for (int base = s; base < e; base += kWave) {
+        const int k = base + lane;
+        const bool valid = k < e;
+        int col = 0, rl = 0;
+        float v = 0.0f;
+        if (valid) {
+            col = src_col[k];
+            rl = src_row[k];
+            v = src_val[k];
+        }
+        const int p = col >> kPwBits, j = p - p0;
+        const int dest = valid ? atomicAdd(&cursor[j], 1) : 0;
+        if (valid) {
+            acc[dest + shift] = (uint16_t)rl;                  // (k_bs_accs turns rows into accumulators)
+            const int q = interleaved(qp[p] + (dest - tp[p]));
+            c16[q] = (uint16_t)((col & (kPw - 1)) | (dest == tp[p] ? kRunBit : 0));   // the first entry of its tile starts a run
+            pvals[q] = v;
+        }
+    }
+}
+
 // Accumulators of one bin (a wavefront per bin).  A STEP of the sum launch holds 128 entries of the bin: entries 4 l + 2 h and
 // 4 l + 2 h + 1 of piece (256 entries), l = 0..63, h = 0 | 1 -- the launch reads the 128 accumulators, adds, writes them back,
 // so no accumulator may be named twice in a step.  occ = how many entries before this one in its step (first entries of the
@@ -1005,9 +1094,37 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
     int32_t st[2] = {0, 0};
     if (h.nnz > 0) {
         if ((rc = panel_rowloc(h, brow.p, nb, rowloc.p, s))) return rc;
-        k_bs_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), sizeof(int) * 4 * ((size_t)np + 256), s>>>(
-            nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, tiles.p, pm.p, bbase.p, c16.p, pvals.p, acc.p);
-        if ((rc = check("k_bs_fill"))) return rc;
+        bool one_pass = false;
+        if (const char *e = getenv("SPMV_BS_FILL")) one_pass = atoi(e) == 1;   // (A/B runs: the one-pass fill)
+        if (one_pass) {
+            k_bs_fill<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), sizeof(int) * 4 * ((size_t)np + 256), s>>>(
+                nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p, tiles.p, pm.p, bbase.p, c16.p, pvals.p, acc.p);
+            if ((rc = check("k_bs_fill"))) return rc;
+        } else {
+            const int ng = (np + 63) >> kGroupBits;
+            DevPtr<int32_t> tcol;
+            DevPtr<float> tval;
+            DevPtr<uint16_t> trow;
+            const int32_t *src_col = h.d_col_idx;
+            const float *src_val = h.d_vals;
+            const uint16_t *src_row = rowloc.p;
+            if (ng > 1) {                                           // (one group: the bins' CSR ranges are grouped as they are)
+                SPMV_HIP_TRY(tcol.alloc((size_t)h.nnz + 8));
+                SPMV_HIP_TRY(tval.alloc((size_t)h.nnz + 8));
+                SPMV_HIP_TRY(trow.alloc((size_t)h.nnz + 8));
+                k_bs_group<<<dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s>>>(nb, np, brow.p, h.d_row_ptr, h.d_col_idx, h.d_vals, rowloc.p,
+                                                                                 tiles.p, tcol.p, tval.p, trow.p);
+                if ((rc = check("k_bs_group"))) return rc;
+                src_col = tcol.p; src_val = tval.p; src_row = trow.p;
+            }
+            const int64_t nitems64 = (int64_t)ng * nb;
+            if (nitems64 > INT_MAX / 2) { set_error("spmv_csr_plan(panel, binned, scattered products): %lld fill items", (long long)nitems64); return SPMV_ERR_INVALID; }
+            const int nitems = (int)nitems64, nwg = (nitems + 3) / 4;
+            k_bs_place<<<dim3(8u * (unsigned)((nwg + 7) / 8)), dim3(256), 0, s>>>(nb, np, nitems, src_col, src_val, src_row, tiles.p, pm.p,
+                                                                                 bbase.p, c16.p, pvals.p, acc.p);
+            if ((rc = check("k_bs_place"))) return rc;
+            SPMV_HIP_TRY(hipStreamSynchronize(s));                  // the grouped copies are freed here
+        }
         k_bs_runs<<<dim3((unsigned)np), dim3(256), 0, s>>>(nb, np, bm, tiles.p, pm.p, pbase.p, bbase.p, run0.p, offset.p, first_run.p, c16.p);
         if ((rc = check("k_bs_runs"))) return rc;
         const size_t lds = sizeof(int) * 2 * (size_t)rb;
