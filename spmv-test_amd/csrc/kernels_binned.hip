@@ -209,12 +209,12 @@ __global__ __launch_bounds__(kProdThreads) void k_bin_products(int splits, int64
 // 6 B) and stores each product at its bin-major position -- a tile is one contiguous RUN in both orders, so the position is
 // the entry's own index plus its run's offset (4 B per run: run number = the block's first run + the flags counted up to
 // the entry, a ballot per store), and the panel-major arrays are interleaved in blocks of 512 so that the 64 lanes of one
-// store hold 64 CONSECUTIVE entries (16-byte loads per lane AND whole runs per store).  The sum launch is then a pure stream per bin: 4 B of product + a
-// 16-bit ACCUMULATOR index, 256 entries per piece (four consecutive per lane), no tile table at all.  What keeps the
-// read-add-write of a step free of collisions is decided when the plan is made: entry k of every lane forms a step; the
-// j-th entry of a step that names a row already named in it gets the row's j-th spare accumulator (k_bs_accs), the spare
-// accumulators join the row's own at the end of the bin.  A bin that needs more spare accumulators than there are (kPool) is
-// flagged and adds with LDS atomics.
+// store hold 64 CONSECUTIVE entries (16-byte loads per lane AND whole runs per store).  The sum launch is then a pure
+// stream per bin: 4 B of product + a 16-bit ACCUMULATOR index, 256 entries per piece (four consecutive per lane), no tile
+// table at all.  What keeps the read-add-write of a step free of collisions is decided when the plan is made: two entries
+// of every lane form a step of 128; the j-th entry of a step that names a row already named in it gets the row's j-th
+// spare accumulator (k_bs_accs), the spare accumulators join the row's own at the end of the bin.  A bin that needs more
+// spare accumulators than there are (kPool) is flagged and adds with LDS atomics.
 constexpr int kBlk = 512;                  // interleave block of the panel-major arrays: lane l of a wavefront holds entries l, 64 + l, ...
 constexpr int kPool = 1024;                // spare accumulators of a bin (8192 + 1024 + 64 words: four wavefronts per CU)
 constexpr int kBmPiece = 256;              // entries of the bin-major arrays per wavefront instruction group
@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256) void k_bs_runs(int nb, int np, int32_t bm, con
     }
 }
 
-// k_bin_fill for this flavour: rows at the bin-major (padded) position, the panel-major entry interleaved, and its destination
+// k_bin_fill for this flavour, in one pass (SPMV_BS_FILL=1; the plan runs k_bs_group + k_bs_place below): rows at the bin-major
+// (padded) position, the panel-major entry interleaved, the first entry of every tile flagged
 __global__ __launch_bounds__(256) void k_bs_fill(int nb, int np, const int32_t *__restrict__ brow, const int32_t *__restrict__ row_ptr,
                                                  const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
                                                  const uint16_t *__restrict__ rowloc, const int32_t *__restrict__ tile_ptr,
