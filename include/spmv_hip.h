@@ -196,7 +196,10 @@ SPMV_API int spmv_csr_values_changed(spmv_csr_t *h);
  *   params[1] threads per workgroup (ADAPTIVE/TILED: 256 | 512 | 1024; a chunk is 16x that many nonzeros)
  *   params[2] staging-pass budget (TILED)        params[3] 1 = keep the 16-bit column copy where it pays (TILED)
  *   params[4] log2(columns per panel) (PANEL)    params[5] wavefronts per launch (PANEL)
- *   params[6] PANEL: 1 = panels of x gathered through L2, 2 = staged in LDS (0 on input: the library's rule)    params[7] 0
+ *   params[6] PANEL layout: 1 = panel sweep, x gathered through L2; 2 = the sweep with x staged in LDS; 3 = sorted blocks
+ *             (params[4] = rows per block 4096 | 8192, params[5] = wavefronts per workgroup); 4 = binned, the sum launch fetches
+ *             the tiles (params[4] = rows per bin 1024 ... 8192); 5 = binned, the product launch stores in bin order
+ *             (params[4] = rows per bin 4096 | 8192 | 16384); 0 on input: the library's rule                 params[7] 0
  * spmv_csr_plan (the default) derives them from the matrix alone -- no timing -- so two handles of one matrix
  * already agree; handles of DIFFERENT row blocks of one matrix may not, and with SPMV_AUTOTUNE=1 nothing is
  * guaranteed.  spmv_csr_plan_set plans with exactly these numbers (replacing any existing plan of that variant),
