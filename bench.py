@@ -93,8 +93,10 @@ def parse():
                     help="rocSPARSE's best algorithm beside every workload of other_workloads: a child process loads "
                          "librocsparse.so (0.5 GB) and runs it once while this one times the CPU baseline; 'wait' (default) waits "
                          "for that child up to --vendor-wait seconds, 'if-ready' never waits, 'off' skips it")
-    ap.add_argument("--vendor-wait", type=float, default=float(os.environ.get("SPMV_BENCH_VENDOR_WAIT", "120")),
-                    help="'wait': give up on rocSPARSE this many seconds after its warm-up child was started (default 120)")
+    ap.add_argument("--vendor-wait", type=float, default=float(os.environ.get("SPMV_BENCH_VENDOR_WAIT", "200")),
+                    help="'wait': give up on rocSPARSE this many seconds after its warm-up child was started (default 200; this process's "
+                         "own first load of the library comes on top: 0-170 s by box, a thread with libc's dlopen was tried and "
+                         "changes nothing -- the interpreter's other loads queue behind it)")
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 23)
     ap.add_argument("--rows-per-gpu", type=int, default=16 << 20, help="N>1: rows of each rank's block (default 16Mi)")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SPMV_BENCH_PIPELINE", "4")),
