@@ -361,3 +361,25 @@ def test_scattered_edge_shapes_inf_nan_and_stale_values(pkg, oracle, gpu):
     y64, mag = oracle.spmv_f64(rp, ci, 2.0 * va, x2)
     assert_close_to_oracle(prob.d_y[:rows].cpu().numpy(), y64, mag, "binned scattered after re-plan")
     prob.A.close()
+
+
+def test_scattered_one_pass_fill_gives_the_same_product(pkg, oracle, gpu):
+    """SPMV_BS_FILL=1: the plan's one-pass fill (rows ascending inside a tile) instead of the two passes (groups of 64 panels, then
+    tiles; the order inside a tile is what the LDS atomics hand out) -- another order of the same sums: both within the bound,
+    each one bit-identical to itself on a second handle (the synthetic-law test checks that for the default)."""
+    import torch
+    capi = pkg.capi
+    w = pkg.workloads.config("c4", band=0, scale=1 / 16)          # 32 panels: one group; and c2 at full size: 32 panels too
+    for wl in (w, pkg.workloads.config("c3", band=0, scale=1 / 4), pkg.workloads.Workload("wide", 1 << 16, 1 << 23, "const", 16, band=0)):
+        prob = synth_problem(pkg, oracle, gpu, wl)
+        y64, mag = oracle.spmv_f64(prob.row_ptr, prob.col_idx, prob.vals, prob.x)
+        ys = []
+        for fill in ("0", "1"):
+            os.environ["SPMV_BS_FILL"] = fill
+            try:
+                y = _run(prob, capi, 8192, mode=5)
+            finally:
+                os.environ.pop("SPMV_BS_FILL", None)
+            assert_close_to_oracle(y, y64, mag, f"scattered, SPMV_BS_FILL={fill}: {wl.name}")
+            ys.append(y)
+        prob.A.close()
