@@ -374,6 +374,10 @@ static int plan_auto(spmv_csr &h, hipStream_t s)
         if (const char *e = getenv("SPMV_AUTO_BINNED")) try_binned = atoi(e) != 0 ? try_binned : 0;   // 0: never (A/B runs)
         if (try_binned) {
             rc = build_panel(h, h.plan_auto_panel, 0, 0, try_binned, s);
+            // (bins that ran out of spare accumulators add with LDS atomics, four times slower: rows with dozens of nonzeros in
+            // one tile -- long rows over a band of a few million columns -- are the fetching flavour's case)
+            if (rc == SPMV_OK && try_binned == 5 && 32 * (int64_t)h.plan_auto_panel.flagged_tiles > h.plan_auto_panel.nblocks)
+                rc = build_panel(h, h.plan_auto_panel, 0, 0, 4, s);
             if (rc == SPMV_OK) {
                 h.auto_variant = SPMV_PANEL;
                 release_tiled();

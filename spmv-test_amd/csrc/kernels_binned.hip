@@ -441,8 +441,19 @@ __global__ __launch_bounds__(256) void k_bs_place(int nb, int np, int nitems, co
             v = src_val[k];
         }
         const int p = col >> kPwBits, j = p - p0;
-        const int dest = valid ? atomicAdd(&cursor[j], 1) : 0;
+        int dest = valid ? atomicAdd(&cursor[j], 1) : 0;
         if (valid) {
+            // The places come in CSR order, a row's nonzeros of the tile next to each other -- and a step of the sum launch takes
+            // its 128 entries from a piece of 256 consecutive ones: a row with two nonzeros in the tile (rows of 33 and more over a
+            // band of two million columns: a tenth of config 4's rows) would need a spare accumulator, a row of 32 in the tile 31
+            // (config 4, band 2M: every bin over its 1024 and on the atomics, 2.3 ms).  Neighbours are dealt a piece apart
+            // instead: the first 256 M entries of the tile (M = its entries / 256) as a 256 x M grid written column by column
+            const int t0 = tp[p], len = tp[p + 1] - t0, m = len >> 8;
+            const int r = dest - t0;
+            if (m >= 2 && r < (m << 8)) {
+                const int a = (int)((unsigned)r / (unsigned)m), bq = r - a * m;
+                dest = t0 + (bq << 8) + a;
+            }
             acc[dest + shift] = (uint16_t)rl;                  // (k_bs_accs turns rows into accumulators)
             const int q = interleaved(qp[p] + (dest - tp[p]));
             c16[q] = (uint16_t)((col & (kPw - 1)) | (dest == tp[p] ? kRunBit : 0));   // the first entry of its tile starts a run
