@@ -594,15 +594,19 @@ __global__ __launch_bounds__(kProdThreads) void k_bs_products(int splits, int np
     const int part = blockIdx.x - p * splits;
 #ifndef SPMV_BS_AB_NOXCD
     if (splits == 1) {
-        // Workgroups go round the eight XCDs; an XCD takes a contiguous EIGHTH of the panels.  Tiles (b, p) and (b, p + 1) are
-        // neighbours in the bin-major products and share a 128-byte line: written through ONE L2 a few microseconds apart the
-        // line leaves it whole; written through two, each L2 writes its part back under a byte mask
-        // (config 5's shard: 1.63 -> 1.36 ms, profiles/r04_scattered_products_xcd.jsonl)
-        const int per8 = (np + 7) >> 3;
-        p = (int)(blockIdx.x & 7u) * per8 + (int)(blockIdx.x >> 3);
-        if (p >= np) return;                                        // (the grid is 8 per8 workgroups)
+        // Workgroups go round the eight XCDs; an XCD takes the panels in CHUNKS of 32 consecutive ones (what its 32 CUs run at
+        // a time), the chunks dealt round the XCDs.  Tiles (b, p) and (b, p + 1) are neighbours in the bin-major products and
+        // share a 128-byte line: written through ONE L2 a few microseconds apart the line leaves it whole; written through two,
+        // each L2 writes its part back under a byte mask (config 5's shard: 1.63 -> 1.36 ms,
+        // profiles/r04_scattered_products_xcd.jsonl).  (First form: an XCD took a contiguous EIGHTH of the panels -- on a banded
+        // shard whose nonzeros sit in the first eighth of the columns one XCD did all the work: 3.0 ms at config 5's shard with
+        // a band of 200 000 ... 4M columns.)
+        const int x8 = (int)(blockIdx.x & 7u), i = (int)(blockIdx.x >> 3);
+        p = (((i >> 5) << 3) + x8) * 32 + (i & 31);
+        if (p >= np) return;                                        // (the grid: 8 XCDs x 32 x ceil(np / 256) workgroups)
     }
 #endif
+    if (pbase[p] == pbase[p + 1]) return;                           // (an empty panel: nothing to stage x for)
     const int64_t g0 = (int64_t)p << kPwBits;
     if (g0 + kPw + 3 < cols) {                                      // workgroup-uniform
 #pragma unroll
@@ -1364,7 +1368,7 @@ int launch_binned(const spmv_csr &h, const PanelPlan &p, const float *x, float *
         const size_t lds = sizeof(float) * (size_t)kPw;
         static LdsOptIn optin;
         if (int rc = optin.ensure(reinterpret_cast<const void *>(&k_bs_products), h.device, (int)lds)) return rc;
-        const unsigned grid = p.splits == 1 ? 8u * (unsigned)((p.npanels + 7) / 8) : (unsigned)(p.npanels * p.splits);
+        const unsigned grid = p.splits == 1 ? 256u * (unsigned)((p.npanels + 255) / 256) : (unsigned)(p.npanels * p.splits);
         k_bs_products<<<dim3(grid), dim3(kProdThreads), lds, s>>>(p.splits, p.npanels, h.cols, p.d_pbase, p.d_c16,
                                                                                               p.d_pvals, p.d_first_run, p.d_offset, x, p.d_prod);
         if (int rc = check("k_bs_products")) return rc;
