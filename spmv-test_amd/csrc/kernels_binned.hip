@@ -29,6 +29,7 @@
 #include <climits>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 #include "spmv_internal.hpp"
 
 namespace spmv {
@@ -1160,8 +1161,18 @@ static int plan_scatter(spmv_csr &h, PanelPlan &p, int rb, int32_t padded, DevPt
     } else {
         SPMV_HIP_TRY(hipMemsetAsync(nlong.p, 0, sizeof(int32_t) * (size_t)nb, s));
     }
+    // the product launch: at least two rounds of CUs over the panels that HOLD something (a banded shard fills a fraction of
+    // its panels), their streams shared by `splits` workgroups where they are fewer
     const int cus = device_cus(h.device);
-    p.splits = np >= 2 * cus ? 1 : (2 * cus + np - 1) / np;
+    {
+        std::vector<int32_t> hb((size_t)np + 1);
+        SPMV_HIP_TRY(hipMemcpyAsync(hb.data(), pbase.p, sizeof(int32_t) * ((size_t)np + 1), hipMemcpyDeviceToHost, s));
+        SPMV_HIP_TRY(hipStreamSynchronize(s));
+        int holding = 0;
+        for (int q = 0; q < np; ++q) holding += hb[(size_t)q + 1] > hb[(size_t)q] ? 1 : 0;
+        if (holding < 1) holding = 1;
+        p.splits = holding >= 2 * cus ? 1 : (2 * cus + holding - 1) / holding;
+    }
     if (const char *e = getenv("SPMV_BINNED_SPLITS")) { const int v = atoi(e); if (v > 0) p.splits = v; }
     if ((rc = stamp_values(h, s, p.stamp))) return rc;
     SPMV_HIP_TRY(hipStreamSynchronize(s));   // the temporaries (tiles, pm, rowloc) are freed on return
