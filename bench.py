@@ -697,6 +697,18 @@ def main():
         else:
             traffic, traffic_source = measure_traffic(args, world=world if (world > 1 or strong) else 1, device=local_rank)
         print(f"[bench] traffic passes done at {time.perf_counter() - t_main:.1f} s: {traffic_source[:90]}", file=sys.stderr, flush=True)
+    # The vendor library is MAPPED now, while this process has no HIP context yet: a library that registers its code objects
+    # with a live context has all of them loaded at once -- 156-180 s of a freshly booted box for librocsparse.so's 0.5 GB,
+    # spent inside the first comparison -- while one registered before the context exists loads what is launched, when it is
+    vendor_early = None
+    if single and rank == 0 and args.vendor != "off" and not args.no_extras:
+        try:
+            import ctypes
+            t_e = time.perf_counter()
+            vendor_early = ctypes.CDLL("/opt/rocm/lib/librocsparse.so")
+            print(f"[bench] librocsparse.so mapped at {time.perf_counter() - t_main:.1f} s ({time.perf_counter() - t_e:.1f} s)", file=sys.stderr, flush=True)
+        except OSError as ex:
+            print(f"[bench] librocsparse.so: {ex}", file=sys.stderr, flush=True)
 
     import torch
     import torch.distributed as dist
